@@ -1,0 +1,198 @@
+/*
+ * magic_hip.h -- C ABI of libmagic_hip.so, the MI355X (gfx950) implementation of the
+ * MAGIC masked-GAT auto-encoder hot path and KNN outlier scorer.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless a comment says "host";
+ *   - every function returns 0 (MAGIC_OK) or a negative magic_status; none throws,
+ *     exits or synchronises the device; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*, NULL = the default stream);
+ *   - the library allocates nothing: scratch comes in through `workspace`, whose size the
+ *     matching *_workspace_bytes() function reports;
+ *   - "CSC order" = edges sorted by destination node, ties by ascending original edge id;
+ *     "CSR order" = sorted by source node, same tie rule;
+ *   - row strides (`ld_*`) are in elements, not bytes.
+ *
+ * The reference has no FFI: its seam is the Python API of model/gat.py,
+ * model/autoencoder.py and model/eval.py plus the DGL / scikit-learn calls those files
+ * make.  Each entry point names the reference lines (relative to the reference tree) whose
+ * third-party call it replaces.
+ */
+#ifndef MAGIC_HIP_H
+#define MAGIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum magic_status {
+    MAGIC_OK = 0,
+    MAGIC_ERR_INVALID_ARG = -1,   /* null pointer, negative size, inconsistent sizes */
+    MAGIC_ERR_UNSUPPORTED = -2,   /* head count / head width without a compiled kernel */
+    MAGIC_ERR_WORKSPACE = -3,     /* workspace missing or too small */
+    MAGIC_ERR_LAUNCH = -4,        /* hipGetLastError() reported a launch failure */
+    MAGIC_ERR_RUNTIME = -5        /* another HIP runtime call failed */
+} magic_status;
+
+/* Library ABI version (bumped on any signature change). */
+int magic_abi_version(void);
+/* Static, human readable text for a status code. */
+const char *magic_status_string(int status);
+
+/* ------------------------------------------------------------------------------------
+ * Per-kernel timing (HIP events on the launch stream).  While enabled, every kernel the
+ * library launches is bracketed by two events; magic_prof_read() synchronises those
+ * events and returns, per kernel name, the launch count and the summed duration.
+ * Has no counterpart in the reference (which has no timers: model/eval.py:7 imports
+ * `time` and never uses it).
+ * ---------------------------------------------------------------------------------- */
+int magic_prof_enable(int on);
+int magic_prof_reset(void);
+/* host buffers; returns number of distinct kernels written (<= max_entries) or <0 */
+int magic_prof_read(int max_entries, char *names /* max_entries x 64 bytes */,
+                    int64_t *launches, double *total_ms);
+
+/* ------------------------------------------------------------------------------------
+ * CSC + CSR construction: stable counting sort of the COO edge list by destination and
+ * by source.  Replaces DGL's lazy COO->CSR/CSC conversion behind every message-passing
+ * call of the reference (model/gat.py:302-303 apply_edges, :308 edge_softmax,
+ * :311-312 update_all) and, through offset concatenation on the host side, dgl.batch
+ * (model/train.py:39).  Integer work: results are bit-exact.
+ * ---------------------------------------------------------------------------------- */
+int magic_csr_build_workspace_bytes(int64_t n_nodes, int64_t n_edges, size_t *bytes /* host */);
+int magic_csr_build(int64_t n_nodes, int64_t n_edges,
+                    const int64_t *src, const int64_t *dst,            /* [E] COO, DGL's int64 ids */
+                    int32_t *in_ptr, int32_t *in_src, int32_t *in_eid,    /* [N+1],[E],[E] CSC */
+                    int32_t *out_ptr, int32_t *out_dst, int32_t *out_eid, /* [N+1],[E],[E] CSR */
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Segment work plan shared by the GAT kernels.  Segments (in-edges of one destination in
+ * CSC order, out-edges of one source in CSR order) of at most `light_max` edges are
+ * reduced by one lane group inside the fused kernels; longer ones ("heavy") are cut into
+ * chunks that separate waves reduce, combined in chunk order.
+ * ---------------------------------------------------------------------------------- */
+typedef struct magic_plan {
+    const int32_t *ptr;        /* [N+1] segment offsets */
+    int32_t light_max;         /* segments longer than this are heavy */
+    int32_t n_heavy;           /* number of heavy nodes */
+    const int32_t *heavy_node; /* [n_heavy] node id */
+    const int32_t *heavy_cptr; /* [n_heavy+1] first chunk of each heavy node */
+    int32_t n_chunks;
+    const int32_t *chunk_node; /* [n_chunks] heavy slot (index into heavy_node) */
+    const int32_t *chunk_beg;  /* [n_chunks] first edge of the chunk */
+    const int32_t *chunk_end;  /* [n_chunks] one past the last edge */
+} magic_plan;
+
+/* ------------------------------------------------------------------------------------
+ * Dense node projection with fused attention scores.
+ *   Y[n, :] = X[n, :] . W^T                                   X [N,F], W [M,F] row-major
+ * Columns of Y are split into up to three outputs so that the gathered operand keeps
+ * 128-byte aligned rows:  cols [0,C) -> hs [N,C];  cols [C, C+n_score) -> score [N,n_score]
+ * (eh then et, model/gat.py:291-292, pre-folded into W by the caller);  cols
+ * [C+n_score, M) -> res [N, M-C-n_score] (residual projection, model/gat.py:323).
+ * Replaces torch.nn.Linear at model/gat.py:284 and :323.  fp32 in, fp32 accumulate
+ * (v_mfma_f32_32x32x2_f32, bit-equal to an fmaf chain over k).
+ * ---------------------------------------------------------------------------------- */
+int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_score, int32_t res_c,
+                   const float *x, int64_t ld_x, const float *w /* [C+n_score+res_c, in_dim] */,
+                   float *hs, int64_t ld_hs, float *score, float *res, int64_t ld_res,
+                   void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * One edge-feature-aware GAT layer, edge phase (model/gat.py:302-335):
+ *   logit[e,h] = leaky_relu(eh[src e,h] + ee[e,h] + et[dst e,h])           (:302-307)
+ *   a[e,h]     = softmax over the in-edges of dst e                        (:308)
+ *   agg[v,h,:] = sum_{e: dst e = v} a[e,h] * hs[src e,h,:]                 (:311-312)
+ *   pre[v]     = agg[v] + bias + res[v]                                    (:316-324)
+ *   out[v]     = pre >= 0 ? pre : prelu_w * pre      (when prelu_w != NULL) (:334-335)
+ * ee comes either from a per-edge-type table (`ee_table[e_dim,H]` + `etype_csc[E]`; edge
+ * attributes are one-hot, utils/loaddata.py:259) or from a dense `ee_csc[E,H]` array.
+ * H*D must be one of the compiled shapes (D in {4,8,16,32,64}, H*D/4 a power of two
+ * <= 64); callers zero-pad narrower heads.
+ * Outputs: out [N,H*D]; pre [N,H*D] (optional, needed by backward when prelu_w is given);
+ * attn [E,H] in CSC order with the SIGN BIT set where the pre-activation logit was
+ * negative (|attn| is the attention weight; backward needs the sign for leaky_relu').
+ * ---------------------------------------------------------------------------------- */
+size_t magic_gat_fwd_workspace_bytes(int32_t n_chunks, int32_t n_heads, int32_t head_dim);
+int magic_gat_fwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t head_dim,
+                  const magic_plan *in_plan /* host struct of device pointers */,
+                  const int32_t *in_src,
+                  const float *hs, int64_t ld_hs,
+                  const float *eh, const float *et, int64_t ld_score /* row stride of eh and et */,
+                  const float *ee_table, const int32_t *etype_csc, const float *ee_csc,
+                  float negative_slope, const float *bias, const float *res, int64_t ld_res,
+                  const float *prelu_w,
+                  float *out, int64_t ld_out, float *pre, float *attn,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Backward of magic_gat_fwd (DGL's EdgeSoftmax / GSpMM / GSDDMM backward + the PReLU,
+ * bias and residual adjoints that torch autograd runs for model/gat.py:302-335).
+ * Inputs: the forward's hs, attn, pre; d_out [N,H*D].
+ * Outputs:
+ *   d_pre  [N,ld_dpre] gradient w.r.t. the pre-activation (= gradient of the residual input)
+ *   d_y    [N,ld_dy] cols [0,C) d_hs, [C,C+H) d_eh, [C+H,C+2H) d_et  (C = H*D)
+ *   d_ee_table [e_dim,H] (when etype_csc != NULL)   -- fixed-order reduction, no atomics
+ *   edge_rec [E,2H]  CSC order: {a[0..H), d_logit[0..H)}; d_logit is the gradient w.r.t.
+ *                    ee[e,:] for the dense-ee path
+ *   d_bias [H*D] (optional), d_prelu_w [1] (optional)
+ * ---------------------------------------------------------------------------------- */
+size_t magic_gat_bwd_workspace_bytes(int32_t n_nodes, int32_t n_edges, int32_t n_chunks_in,
+                                     int32_t n_chunks_out, int32_t n_heads, int32_t head_dim,
+                                     int32_t e_dim);
+int magic_gat_bwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t head_dim,
+                  const magic_plan *in_plan, const int32_t *in_src,
+                  const magic_plan *out_plan, const int32_t *out_dst, const int32_t *out_pos,
+                  const float *hs, int64_t ld_hs, const float *attn,
+                  const int32_t *etype_csc, int32_t e_dim,
+                  float negative_slope, const float *pre, const float *prelu_w,
+                  const float *d_out, int64_t ld_dout,
+                  float *d_pre, int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table,
+                  float *edge_rec,
+                  float *d_bias, float *d_prelu_w,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Masked-node feature reconstruction loss, forward and backward in one pass
+ * (model/autoencoder.py:242-245 + model/loss_func.py:28-31):
+ *   loss = mean_i (1 - cos(x_rec[mask i], target_i))^alpha,  F.normalize eps = 1e-12.
+ * target_i is row mask[i] of `target` (ld_t > 0) or the single row `target` (ld_t == 0:
+ * the mask token, which is what DGL's shared-storage clone leaves in g.ndata['attr']).
+ * Writes loss[1], d_x [N, ld_x] (zero outside the masked rows, scaled by `grad_scale`)
+ * and, when d_target_row != NULL, the summed gradient of the single target row.
+ * ---------------------------------------------------------------------------------- */
+size_t magic_sce_workspace_bytes(int64_t n_mask, int32_t n_dim);
+int magic_sce_fwd_bwd(int64_t n_rows, int32_t n_dim, int64_t n_mask, const int64_t *mask_idx,
+                      const float *x, int64_t ld_x, const float *target, int64_t ld_t,
+                      float alpha, float grad_scale,
+                      float *loss, float *d_x, float *d_target_row,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Brute-force k nearest neighbours (Euclidean), replacing
+ * sklearn.neighbors.NearestNeighbors(...).kneighbors at model/eval.py:154,158 and
+ * :306,311.  Squared distances |q|^2 - 2 q.t + |t|^2 are formed in float64 on the f64
+ * matrix cores from float32 inputs (as scikit-learn's float32 path does), the k
+ * smallest per query are kept, ordered by (distance, train index), then sqrt.
+ * `train_index_offset` is added to every returned index (row offset of this shard of the
+ * train set).  magic_knn_merge combines `n_parts` such results (e.g. one per train
+ * shard / per GPU) into the global k best, same order rule.
+ * ---------------------------------------------------------------------------------- */
+size_t magic_knn_workspace_bytes(int64_t n_train, int64_t n_query, int32_t dim, int32_t k);
+int magic_knn_topk(int64_t n_train, int64_t n_query, int32_t dim, int32_t k,
+                   const float *train, int64_t ld_train, const float *query, int64_t ld_query,
+                   int64_t train_index_offset,
+                   double *dist /* [Q,k] */, int64_t *idx /* [Q,k] */,
+                   void *workspace, size_t workspace_bytes, void *stream);
+int magic_knn_merge(int64_t n_query, int32_t k, int32_t n_parts,
+                    const double *part_dist /* [n_parts,Q,k] */, const int64_t *part_idx,
+                    double *dist, int64_t *idx, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGIC_HIP_H */

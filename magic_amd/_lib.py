@@ -1,0 +1,304 @@
+"""ctypes binding of ``libmagic_hip.so`` (C ABI declared in ``include/magic_hip.h``).
+
+PyTorch is used here only as the owner of device memory and of the HIP stream:
+every call passes raw device pointers, sizes and the current stream handle.
+There is no CPU fallback: if the shared library is missing, or a tensor is not on
+the GPU, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmagic_hip.so")
+_lib = None
+
+c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+
+class MagicPlan(C.Structure):
+    _fields_ = [("ptr", c_vp), ("light_max", c_i32), ("n_heavy", c_i32), ("heavy_node", c_vp),
+                ("heavy_cptr", c_vp), ("n_chunks", c_i32), ("chunk_node", c_vp), ("chunk_beg", c_vp),
+                ("chunk_end", c_vp)]
+
+
+# name -> (restype, argtypes); must list every symbol include/magic_hip.h declares
+SYMBOLS = {
+    "magic_abi_version": (c_i32, []),
+    "magic_status_string": (C.c_char_p, [c_i32]),
+    "magic_prof_enable": (c_i32, [c_i32]),
+    "magic_prof_reset": (c_i32, []),
+    "magic_prof_read": (c_i32, [c_i32, C.c_char_p, C.POINTER(c_i64), C.POINTER(C.c_double)]),
+    "magic_csr_build_workspace_bytes": (c_i32, [c_i64, c_i64, C.POINTER(c_sz)]),
+    "magic_csr_build": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "magic_proj_fwd": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp,
+                               c_i64, c_vp]),
+    "magic_gat_fwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
+    "magic_gat_fwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp,
+                              c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp,
+                              c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "magic_gat_bwd_workspace_bytes": (c_sz, [c_i32] * 7),
+    "magic_gat_bwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, C.POINTER(MagicPlan), c_vp,
+                              c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_i64,
+                              c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "magic_sce_workspace_bytes": (c_sz, [c_i64, c_i32]),
+    "magic_sce_fwd_bwd": (c_i32, [c_i64, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32,
+                                  c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "magic_knn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32]),
+    "magic_knn_topk": (c_i32, [c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp,
+                               c_vp, c_sz, c_vp]),
+    "magic_knn_merge": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+}
+
+
+class MagicHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """dlopen the library once and set every prototype; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise MagicHipError(
+            f"{_LIB_PATH} not found: build it with `make -C magic_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(status: int, what: str):
+    if status != 0:
+        msg = load().magic_status_string(status).decode()
+        raise MagicHipError(f"{what} failed: {msg} (status {status})")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: Optional[torch.Tensor], dtype=None, name="tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if t.device.type != "cuda":
+        raise MagicHipError(f"{name} must live on the GPU (got {t.device}); there is no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise MagicHipError(f"{name} must be {dtype} (got {t.dtype})")
+    return t.data_ptr()
+
+
+_ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, slot); kernels on one stream run in order, so
+    consecutive calls can share it."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------- profiling
+def prof_enable(on: bool):
+    _check(load().magic_prof_enable(1 if on else 0), "magic_prof_enable")
+
+
+def prof_reset():
+    _check(load().magic_prof_reset(), "magic_prof_reset")
+
+
+def prof_read(max_entries: int = 64):
+    names = C.create_string_buffer(max_entries * 64)
+    launches = (c_i64 * max_entries)()
+    total = (C.c_double * max_entries)()
+    n = load().magic_prof_read(max_entries, names, launches, total)
+    if n < 0:
+        _check(n, "magic_prof_read")
+    out = {}
+    for i in range(n):
+        nm = names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()
+        out[nm] = (int(launches[i]), float(total[i]))
+    return out
+
+
+# ------------------------------------------------------------------------------------- CSR
+def csr_build(src: torch.Tensor, dst: torch.Tensor, num_nodes: int):
+    lib = load()
+    E = int(src.numel())
+    dev = src.device
+    src = src.contiguous().to(torch.int64)
+    dst = dst.contiguous().to(torch.int64)
+    i32 = torch.int32
+    in_ptr = torch.empty(num_nodes + 1, dtype=i32, device=dev)
+    out_ptr = torch.empty(num_nodes + 1, dtype=i32, device=dev)
+    in_src, in_eid, out_dst, out_eid = (torch.empty(E, dtype=i32, device=dev) for _ in range(4))
+    nbytes = c_sz(0)
+    _check(lib.magic_csr_build_workspace_bytes(num_nodes, E, C.byref(nbytes)), "magic_csr_build_workspace_bytes")
+    ws = workspace(nbytes.value, dev)
+    _check(lib.magic_csr_build(num_nodes, E, _dev(src, torch.int64, "src"), _dev(dst, torch.int64, "dst"),
+                               _dev(in_ptr), _dev(in_src), _dev(in_eid), _dev(out_ptr), _dev(out_dst),
+                               _dev(out_eid), ws.data_ptr(), ws.numel(), _stream()), "magic_csr_build")
+    return in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid
+
+
+def make_plan(plan, light_max: int) -> MagicPlan:
+    """ctypes view of a graph.SegmentPlan (keeps no references: the caller holds the tensors)."""
+    p = MagicPlan()
+    p.ptr = plan.ptr.data_ptr()
+    p.light_max = light_max
+    p.n_heavy = plan.n_heavy
+    p.heavy_node = plan.heavy_node.data_ptr() if plan.n_heavy else None
+    p.heavy_cptr = plan.heavy_cptr.data_ptr() if plan.n_heavy else None
+    p.n_chunks = plan.n_chunks
+    p.chunk_node = plan.chunk_node.data_ptr() if plan.n_chunks else None
+    p.chunk_beg = plan.chunk_beg.data_ptr() if plan.n_chunks else None
+    p.chunk_end = plan.chunk_end.data_ptr() if plan.n_chunks else None
+    return p
+
+
+# ------------------------------------------------------------------------------------- projection
+def proj_fwd(x: torch.Tensor, w: torch.Tensor, out_c: int, n_score: int, res_c: int):
+    """hs [N,out_c], score [N,n_score] | None, res [N,res_c] | None  =  split(x @ w.T)."""
+    lib = load()
+    assert x.dim() == 2 and w.dim() == 2 and w.shape[1] == x.shape[1] and w.shape[0] == out_c + n_score + res_c
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    w = w.contiguous()
+    N, F = x.shape
+    dev = x.device
+    hs = torch.empty(N, out_c, dtype=torch.float32, device=dev)
+    score = torch.empty(N, n_score, dtype=torch.float32, device=dev) if n_score else None
+    res = torch.empty(N, res_c, dtype=torch.float32, device=dev) if res_c else None
+    _check(lib.magic_proj_fwd(N, F, out_c, n_score, res_c, _dev(x, torch.float32, "x"), x.stride(0),
+                              _dev(w, torch.float32, "w"), _dev(hs), out_c, _dev(score), _dev(res), res_c,
+                              _stream()), "magic_proj_fwd")
+    return hs, score, res
+
+
+# ------------------------------------------------------------------------------------- GAT
+def gat_fwd(struct, H: int, D: int, hs, eh, et, ee_table, etype_csc, ee_csc, slope: float, bias, res,
+            prelu_w, want_pre: bool):
+    lib = load()
+    from .graph import LIGHT_MAX
+    N, E = struct.num_nodes, struct.num_edges
+    dev = hs.device
+    Cc = H * D
+    out = torch.empty(N, Cc, dtype=torch.float32, device=dev)
+    pre = torch.empty(N, Cc, dtype=torch.float32, device=dev) if want_pre else None
+    attn = torch.empty(E, H, dtype=torch.float32, device=dev)
+    plan = make_plan(struct.plan_in, LIGHT_MAX)
+    nbytes = lib.magic_gat_fwd_workspace_bytes(struct.plan_in.n_chunks, H, D)
+    ws = workspace(nbytes, dev)
+    _check(lib.magic_gat_fwd(N, E, H, D, C.byref(plan), _dev(struct.in_src),
+                             _dev(hs, torch.float32, "hs"), hs.stride(0), _dev(eh, torch.float32, "eh"),
+                             _dev(et, torch.float32, "et"), eh.stride(0), _dev(ee_table), _dev(etype_csc), _dev(ee_csc),
+                             float(slope), _dev(bias), _dev(res), res.stride(0) if res is not None else 0,
+                             _dev(prelu_w), _dev(out), Cc, _dev(pre), _dev(attn),
+                             ws.data_ptr(), ws.numel(), _stream()), "magic_gat_fwd")
+    return out, pre, attn
+
+
+def gat_bwd(struct, H: int, D: int, hs, attn, etype_csc, e_dim: int, slope: float, pre, prelu_w, d_out,
+            d_pre, d_y, want_bias: bool):
+    """Fills d_pre [N,>=C] and d_y [N,>=C+2H] (views allowed, unit inner stride);
+    returns (d_ee_table | None, edge_rec [E,2H], d_bias | None, d_prelu_w | None)."""
+    lib = load()
+    from .graph import LIGHT_MAX
+    N, E = struct.num_nodes, struct.num_edges
+    dev = hs.device
+    Cc = H * D
+    rec = torch.empty(E, 2 * H, dtype=torch.float32, device=dev)
+    d_table = torch.empty(e_dim, H, dtype=torch.float32, device=dev) if etype_csc is not None else None
+    d_bias = torch.empty(Cc, dtype=torch.float32, device=dev) if want_bias else None
+    d_prelu = torch.empty(1, dtype=torch.float32, device=dev) if prelu_w is not None else None
+    pin = make_plan(struct.plan_in, LIGHT_MAX)
+    pout = make_plan(struct.plan_out, LIGHT_MAX)
+    nbytes = lib.magic_gat_bwd_workspace_bytes(N, E, struct.plan_in.n_chunks, struct.plan_out.n_chunks, H, D,
+                                               max(e_dim, 1))
+    ws = workspace(nbytes, dev)
+    if d_out.stride(1) != 1:
+        d_out = d_out.contiguous()
+    _check(lib.magic_gat_bwd(N, E, H, D, C.byref(pin), _dev(struct.in_src), C.byref(pout), _dev(struct.out_dst),
+                             _dev(struct.out_pos), _dev(hs, torch.float32, "hs"), hs.stride(0),
+                             _dev(attn, torch.float32, "attn"), _dev(etype_csc), int(e_dim), float(slope),
+                             _dev(pre), _dev(prelu_w), _dev(d_out, torch.float32, "d_out"), d_out.stride(0),
+                             _dev(d_pre), d_pre.stride(0), _dev(d_y), d_y.stride(0), _dev(d_table), _dev(rec),
+                             _dev(d_bias), _dev(d_prelu), ws.data_ptr(), ws.numel(), _stream()), "magic_gat_bwd")
+    return d_table, rec, d_bias, d_prelu
+
+
+# ------------------------------------------------------------------------------------- SCE
+def sce_fwd_bwd(x: torch.Tensor, n_dim: int, target: torch.Tensor, single_row: bool, mask_idx: torch.Tensor,
+                alpha: float):
+    """Returns (loss[1], d_x like x, d_target_row[n_dim] | None)."""
+    lib = load()
+    dev = x.device
+    assert x.stride(1) == 1
+    N = x.shape[0]
+    mask_idx = mask_idx.contiguous().to(torch.int64)
+    M = int(mask_idx.numel())
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    d_x = torch.empty_strided((N, x.stride(0)), (x.stride(0), 1), dtype=torch.float32, device=dev)
+    d_t = torch.empty(n_dim, dtype=torch.float32, device=dev) if single_row else None
+    if single_row:
+        target = target.contiguous().view(-1)
+        ld_t = 0
+    else:
+        assert target.stride(1) == 1
+        ld_t = target.stride(0)
+    nbytes = lib.magic_sce_workspace_bytes(M, n_dim)
+    ws = workspace(nbytes, dev)
+    _check(lib.magic_sce_fwd_bwd(N, n_dim, M, _dev(mask_idx), _dev(x, torch.float32, "x"), x.stride(0),
+                                 _dev(target, torch.float32, "target"), ld_t, float(alpha), 1.0, _dev(loss),
+                                 _dev(d_x), _dev(d_t), ws.data_ptr(), ws.numel(), _stream()), "magic_sce_fwd_bwd")
+    return loss, d_x[:, :x.shape[1]], d_t
+
+
+# ------------------------------------------------------------------------------------- KNN
+def knn_topk(train: torch.Tensor, query: torch.Tensor, k: int, index_offset: int = 0):
+    lib = load()
+    assert train.dim() == 2 and query.dim() == 2 and train.shape[1] == query.shape[1]
+    train = train.contiguous()
+    query = query.contiguous()
+    dev = train.device
+    Nt, d = train.shape
+    Q = query.shape[0]
+    dist = torch.empty(Q, k, dtype=torch.float64, device=dev)
+    idx = torch.empty(Q, k, dtype=torch.int64, device=dev)
+    nbytes = lib.magic_knn_workspace_bytes(Nt, Q, d, k)
+    ws = workspace(nbytes, dev, slot=1)
+    _check(lib.magic_knn_topk(Nt, Q, d, k, _dev(train, torch.float32, "train"), train.stride(0),
+                              _dev(query, torch.float32, "query"), query.stride(0), int(index_offset),
+                              _dev(dist), _dev(idx), ws.data_ptr(), ws.numel(), _stream()), "magic_knn_topk")
+    return dist, idx
+
+
+def knn_merge(part_dist: torch.Tensor, part_idx: torch.Tensor):
+    """[P,Q,k] partial results (each ascending) -> global [Q,k]."""
+    lib = load()
+    P, Q, k = part_dist.shape
+    part_dist = part_dist.contiguous()
+    part_idx = part_idx.contiguous()
+    dist = torch.empty(Q, k, dtype=torch.float64, device=part_dist.device)
+    idx = torch.empty(Q, k, dtype=torch.int64, device=part_dist.device)
+    _check(lib.magic_knn_merge(Q, k, P, _dev(part_dist, torch.float64, "part_dist"),
+                               _dev(part_idx, torch.int64, "part_idx"), _dev(dist), _dev(idx), _stream()),
+           "magic_knn_merge")
+    return dist, idx

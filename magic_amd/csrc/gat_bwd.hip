@@ -1,0 +1,540 @@
+// GAT layer, edge phase, backward.  Two segmented sweeps, no atomics:
+//   destination sweep (CSC): PReLU / bias adjoints, d_a = <hs[src], d_pre[dst]>, softmax
+//     backward d_logit = a (d_a - sum_seg a d_a), leaky-ReLU', d_et, and the per-edge record
+//     {a, d_logit} the source sweep reads;
+//   source sweep (CSR): d_hs[u] = sum_{e: src e = u} a_e d_pre[dst e], d_eh[u] = sum d_logit.
+// Then a fixed-order reduction of d_logit per edge type for the edge-score table.
+#include "gat_common.h"
+
+namespace magic {
+
+struct BwdArgs {
+    int N, E;
+    PlanDev pin;   // CSC plan
+    PlanDev pout;  // CSR plan
+    const int32_t *in_src;
+    const int32_t *out_dst;
+    const int32_t *out_pos;
+    const float *hs;
+    int64_t ld_hs;
+    const float *attn;  // [E,H] packed (sign bit = logit not positive)
+    const int32_t *etype;
+    int e_dim;
+    float slope;
+    const float *pre;
+    const float *prelu_w;
+    const float *d_out;
+    int64_t ld_dout;
+    float *d_pre;  // [N,ld_dpre]
+    int64_t ld_dpre;
+    float *d_y;
+    int64_t ld_dy;
+    float *d_table;  // [e_dim,H]
+    float *rec;      // [E,2H]
+    float *d_bias;   // [C]
+    float *d_prelu;  // [1]
+    // workspace
+    float *ws_bias;   // [grid_light, C]
+    float *ws_prelu;  // [grid_light]
+    int grid_light;
+    float *ws_delta;  // [n_chunks_in, H]
+    float *ws_det;    // [n_chunks_in, H]
+    float *ws_acc;    // [n_chunks_out, C]
+    float *ws_deh;    // [n_chunks_out, H]
+    float *ws_table;  // [grid_table, e_dim*H]
+    int grid_table;
+};
+
+// ---- destination sweep, light segments + node-level adjoints for EVERY node -------------
+template <int H, int LPH>
+__global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a) {
+    constexpr int G = H * LPH;
+    constexpr int NPB = 256 / G;
+    constexpr int C = G * 4;
+    __shared__ float4 red4[256];
+    __shared__ float red1[256];
+    const int g = threadIdx.x % G;
+    const int h = g / LPH;
+    const int slot = threadIdx.x / G;
+    const float pw = a.prelu_w ? a.prelu_w[0] : 1.f;
+    float4 bsum = f4zero();
+    float wsum = 0.f;
+    for (int v = blockIdx.x * NPB + slot; v < a.N; v += gridDim.x * NPB) {
+        float4 go = ld4(a.d_out + (int64_t)v * a.ld_dout + g * 4);
+        if (a.prelu_w) {
+            float4 p = ld4(a.pre + (int64_t)v * C + g * 4);
+            wsum += (p.x < 0.f ? go.x * p.x : 0.f) + (p.y < 0.f ? go.y * p.y : 0.f) +
+                    (p.z < 0.f ? go.z * p.z : 0.f) + (p.w < 0.f ? go.w * p.w : 0.f);
+            go.x = p.x > 0.f ? go.x : pw * go.x;
+            go.y = p.y > 0.f ? go.y : pw * go.y;
+            go.z = p.z > 0.f ? go.z : pw * go.z;
+            go.w = p.w > 0.f ? go.w : pw * go.w;
+        }
+        st4(a.d_pre + (int64_t)v * a.ld_dpre + g * 4, go);
+        add4(bsum, go);
+        const int b = a.pin.ptr[v], e = a.pin.ptr[v + 1];
+        if (e - b > a.pin.light_max) continue;
+        // sweep 1: d_a per edge (parked in the record's d_logit slot) and delta = sum a d_a
+        float delta = 0.f;
+        int i = b;
+        for (; i + 4 <= e; i += 4) {
+            float4 r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)a.in_src[i + j] * a.ld_hs + g * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float da = head_sum<LPH>(dot4(r[j], go));
+                float aw = fabsf(a.attn[(int64_t)(i + j) * H + h]);
+                delta = fmaf(aw, da, delta);
+                a.rec[(int64_t)(i + j) * 2 * H + H + h] = da;
+            }
+        }
+        for (; i < e; ++i) {
+            float4 r = ld4(a.hs + (int64_t)a.in_src[i] * a.ld_hs + g * 4);
+            float da = head_sum<LPH>(dot4(r, go));
+            float aw = fabsf(a.attn[(int64_t)i * H + h]);
+            delta = fmaf(aw, da, delta);
+            a.rec[(int64_t)i * 2 * H + H + h] = da;
+        }
+        // sweep 2: d_logit (every lane re-reads the value it stored itself)
+        float det = 0.f;
+        for (i = b; i < e; ++i) {
+            float ap = a.attn[(int64_t)i * H + h];
+            float aw = fabsf(ap);
+            float da = a.rec[(int64_t)i * 2 * H + H + h];
+            float dl = aw * (da - delta);
+            if (attn_neg(ap)) dl *= a.slope;
+            a.rec[(int64_t)i * 2 * H + h] = aw;
+            a.rec[(int64_t)i * 2 * H + H + h] = dl;
+            det += dl;
+        }
+        if ((g % LPH) == 0) a.d_y[(int64_t)v * a.ld_dy + C + H + h] = det;
+    }
+    // per-block partials of d_bias (per channel) and d_prelu_w, summed in slot order
+    red4[threadIdx.x] = bsum;
+    red1[threadIdx.x] = wsum;
+    __syncthreads();
+    if (slot == 0) {
+        for (int k = 1; k < NPB; ++k) add4(bsum, red4[k * G + g]);
+        st4(a.ws_bias + (int64_t)blockIdx.x * C + g * 4, bsum);
+    }
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 256; ++k) t += red1[k];
+        a.ws_prelu[blockIdx.x] = t;
+    }
+}
+
+// final fixed-order reduction of the per-block partials: block c < C reduces channel c,
+// block C reduces the PReLU-slope partials
+__global__ __launch_bounds__(256) void k_bwd_reduce_bias(BwdArgs a, int C) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float t = 0.f;
+    if (c < C) {
+        for (int k = threadIdx.x; k < a.grid_light; k += 256) t += a.ws_bias[(int64_t)k * C + c];
+    } else {
+        for (int k = threadIdx.x; k < a.grid_light; k += 256) t += a.ws_prelu[k];
+    }
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (c < C) {
+            if (a.d_bias) a.d_bias[c] = red[0];
+        } else if (a.d_prelu) {
+            a.d_prelu[0] = red[0];
+        }
+    }
+}
+
+// ---- destination sweep, heavy segments ---------------------------------------------------
+// step 1: wave per chunk, lane groups take edges round robin: d_a and the chunk's delta
+template <int H, int LPH>
+__global__ __launch_bounds__(256) void k_bwd_dst_heavy1(BwdArgs a) {
+    constexpr int G = H * LPH;
+    constexpr int NSG = 64 / G;
+    constexpr int C = G * 4;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= a.pin.n_chunks) return;
+    const int v = a.pin.heavy_node[a.pin.chunk_node[c]];
+    const int beg = a.pin.chunk_beg[c], end = a.pin.chunk_end[c];
+    const int g = lane % G, sg = lane / G, h = g / LPH;
+    const float4 go = ld4(a.d_pre + (int64_t)v * a.ld_dpre + g * 4);
+    float delta = 0.f;
+    int i = beg + sg;
+    for (; i + 3 * NSG < end; i += 4 * NSG) {
+        float4 r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)a.in_src[i + j * NSG] * a.ld_hs + g * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float da = head_sum<LPH>(dot4(r[j], go));
+            delta = fmaf(fabsf(a.attn[(int64_t)(i + j * NSG) * H + h]), da, delta);
+            a.rec[(int64_t)(i + j * NSG) * 2 * H + H + h] = da;
+        }
+    }
+    for (; i < end; i += NSG) {
+        float4 r = ld4(a.hs + (int64_t)a.in_src[i] * a.ld_hs + g * 4);
+        float da = head_sum<LPH>(dot4(r, go));
+        delta = fmaf(fabsf(a.attn[(int64_t)i * H + h]), da, delta);
+        a.rec[(int64_t)i * 2 * H + H + h] = da;
+    }
+    delta = substream_sum<G>(delta);
+    if (sg == 0 && (g % LPH) == 0) a.ws_delta[(int64_t)c * H + h] = delta;
+}
+
+// step 2: wave per chunk, lane per edge: node delta (chunk order), d_logit, record, chunk d_et
+template <int H>
+__global__ __launch_bounds__(256) void k_bwd_dst_heavy2(BwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= a.pin.n_chunks) return;
+    const int slot = a.pin.chunk_node[c];
+    const int c0 = a.pin.heavy_cptr[slot], c1 = a.pin.heavy_cptr[slot + 1];
+    const int beg = a.pin.chunk_beg[c], end = a.pin.chunk_end[c];
+    float delta[H], det[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float t = 0.f;
+        for (int k = c0 + lane; k < c1; k += 64) t += a.ws_delta[(int64_t)k * H + h];
+        delta[h] = wave_sum(t);
+        det[h] = 0.f;
+    }
+    for (int i = beg + lane; i < end; i += 64) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float ap = a.attn[(int64_t)i * H + h];
+            float aw = fabsf(ap);
+            float da = a.rec[(int64_t)i * 2 * H + H + h];
+            float dl = aw * (da - delta[h]);
+            if (attn_neg(ap)) dl *= a.slope;
+            a.rec[(int64_t)i * 2 * H + h] = aw;
+            a.rec[(int64_t)i * 2 * H + H + h] = dl;
+            det[h] += dl;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float t = wave_sum(det[h]);
+        if (lane == 0) a.ws_det[(int64_t)c * H + h] = t;
+    }
+}
+
+// step 3: wave per heavy node: d_et = sum of chunk partials in chunk order
+template <int H>
+__global__ __launch_bounds__(256) void k_bwd_dst_heavy3(BwdArgs a, int C) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= a.pin.n_heavy) return;
+    const int c0 = a.pin.heavy_cptr[slot], c1 = a.pin.heavy_cptr[slot + 1];
+    const int v = a.pin.heavy_node[slot];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float t = 0.f;
+        for (int k = c0 + lane; k < c1; k += 64) t += a.ws_det[(int64_t)k * H + h];
+        t = wave_sum(t);
+        if (lane == 0) a.d_y[(int64_t)v * a.ld_dy + C + H + h] = t;
+    }
+}
+
+// ---- source sweep ------------------------------------------------------------------------
+template <int H, int LPH>
+__global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
+    constexpr int G = H * LPH;
+    constexpr int NPB = 256 / G;
+    constexpr int C = G * 4;
+    const int g = threadIdx.x % G;
+    const int h = g / LPH;
+    const int slot = threadIdx.x / G;
+    for (int u = blockIdx.x * NPB + slot; u < a.N; u += gridDim.x * NPB) {
+        const int b = a.pout.ptr[u], e = a.pout.ptr[u + 1];
+        if (e - b > a.pout.light_max) continue;
+        float4 acc = f4zero();
+        float deh = 0.f;
+        int j = b;
+        for (; j + 4 <= e; j += 4) {
+            int pos[4];
+            float4 r[4];
+            float w[4], dl[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pos[t] = a.out_pos[j + t];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) r[t] = ld4(a.d_pre + (int64_t)a.out_dst[j + t] * a.ld_dpre + g * 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                w[t] = a.rec[(int64_t)pos[t] * 2 * H + h];
+                dl[t] = a.rec[(int64_t)pos[t] * 2 * H + H + h];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fma4(acc, w[t], r[t]);
+                deh += dl[t];
+            }
+        }
+        for (; j < e; ++j) {
+            int pos = a.out_pos[j];
+            float4 r = ld4(a.d_pre + (int64_t)a.out_dst[j] * a.ld_dpre + g * 4);
+            fma4(acc, a.rec[(int64_t)pos * 2 * H + h], r);
+            deh += a.rec[(int64_t)pos * 2 * H + H + h];
+        }
+        st4(a.d_y + (int64_t)u * a.ld_dy + g * 4, acc);
+        if ((g % LPH) == 0) a.d_y[(int64_t)u * a.ld_dy + C + h] = deh;
+    }
+}
+
+template <int H, int LPH>
+__global__ __launch_bounds__(256) void k_bwd_src_heavy1(BwdArgs a) {
+    constexpr int G = H * LPH;
+    constexpr int NSG = 64 / G;
+    constexpr int C = G * 4;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= a.pout.n_chunks) return;
+    const int beg = a.pout.chunk_beg[c], end = a.pout.chunk_end[c];
+    const int g = lane % G, sg = lane / G, h = g / LPH;
+    float4 acc = f4zero();
+    float deh = 0.f;
+    int j = beg + sg;
+    for (; j + 3 * NSG < end; j += 4 * NSG) {
+        int pos[4];
+        float4 r[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pos[t] = a.out_pos[j + t * NSG];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r[t] = ld4(a.d_pre + (int64_t)a.out_dst[j + t * NSG] * a.ld_dpre + g * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            fma4(acc, a.rec[(int64_t)pos[t] * 2 * H + h], r[t]);
+            deh += a.rec[(int64_t)pos[t] * 2 * H + H + h];
+        }
+    }
+    for (; j < end; j += NSG) {
+        int pos = a.out_pos[j];
+        float4 r = ld4(a.d_pre + (int64_t)a.out_dst[j] * a.ld_dpre + g * 4);
+        fma4(acc, a.rec[(int64_t)pos * 2 * H + h], r);
+        deh += a.rec[(int64_t)pos * 2 * H + H + h];
+    }
+    acc = substream_sum4<G>(acc);
+    deh = substream_sum<G>(deh);
+    if (sg == 0) {
+        st4(a.ws_acc + (int64_t)c * C + g * 4, acc);
+        if ((g % LPH) == 0) a.ws_deh[(int64_t)c * H + h] = deh;
+    }
+}
+
+template <int H, int LPH>
+__global__ __launch_bounds__(256) void k_bwd_src_heavy2(BwdArgs a) {
+    constexpr int G = H * LPH;
+    constexpr int NSGB = 256 / G;
+    constexpr int C = G * 4;
+    __shared__ float4 part[256];
+    __shared__ float part1[256];
+    const int slot = blockIdx.x;
+    const int g = threadIdx.x % G, sg = threadIdx.x / G, h = g / LPH;
+    const int c0 = a.pout.heavy_cptr[slot], c1 = a.pout.heavy_cptr[slot + 1];
+    const int u = a.pout.heavy_node[slot];
+    float4 acc = f4zero();
+    float deh = 0.f;
+    for (int c = c0 + sg; c < c1; c += NSGB) {
+        add4(acc, ld4(a.ws_acc + (int64_t)c * C + g * 4));
+        deh += a.ws_deh[(int64_t)c * H + h];
+    }
+    part[threadIdx.x] = acc;
+    part1[threadIdx.x] = deh;
+    __syncthreads();
+    if (sg == 0) {
+        for (int k = 1; k < NSGB; ++k) {
+            add4(acc, part[k * G + g]);
+            deh += part1[k * G + g];
+        }
+        st4(a.d_y + (int64_t)u * a.ld_dy + g * 4, acc);
+        if ((g % LPH) == 0) a.d_y[(int64_t)u * a.ld_dy + C + h] = deh;
+    }
+}
+
+// ---- d_ee_table[t,h] = sum over edges of type t of d_logit[e,h] ---------------------------
+// Every thread keeps TMAX x H running sums in registers (compare-select per type, no
+// indexing), blocks reduce through LDS in thread order, a last launch adds the block rows.
+template <int H, int TMAX>
+__global__ __launch_bounds__(256) void k_bwd_table_partial(BwdArgs a) {
+    __shared__ float red[256];
+    float acc[TMAX][H];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int h = 0; h < H; ++h) acc[t][h] = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.E; i += gridDim.x * 256) {
+        const int ty = a.etype[i];
+        float dl[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) dl[h] = a.rec[(int64_t)i * 2 * H + H + h];
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+            for (int h = 0; h < H; ++h) acc[t][h] += (ty == t) ? dl[h] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            if (t < a.e_dim) {  // uniform
+                float v = wave_sum(acc[t][h]);
+                __syncthreads();
+                if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    a.ws_table[(int64_t)blockIdx.x * a.e_dim * H + t * H + h] = (red[0] + red[1]) + (red[2] + red[3]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bwd_table_final(BwdArgs a, int H) {
+    const int n = a.e_dim * H;
+    for (int o = threadIdx.x; o < n; o += 256) {
+        float t = 0.f;
+        for (int k = 0; k < a.grid_table; ++k) t += a.ws_table[(int64_t)k * n + o];
+        a.d_table[o] = t;
+    }
+}
+
+template <int H>
+int launch_table(BwdArgs &a, hipStream_t stream) {
+    if (!a.etype || !a.d_table) return MAGIC_OK;
+    if (a.E == 0) {
+        if (hipMemsetAsync(a.d_table, 0, sizeof(float) * a.e_dim * H, stream) != hipSuccess) return MAGIC_ERR_RUNTIME;
+        return MAGIC_OK;
+    }
+    if (a.e_dim <= 8)
+        MAGIC_LAUNCH("gat_bwd_table_partial", (k_bwd_table_partial<H, 8>), a.grid_table, 256, 0, stream, a);
+    else if (a.e_dim <= 16)
+        MAGIC_LAUNCH("gat_bwd_table_partial", (k_bwd_table_partial<H, 16>), a.grid_table, 256, 0, stream, a);
+    else if (a.e_dim <= 24)
+        MAGIC_LAUNCH("gat_bwd_table_partial", (k_bwd_table_partial<H, 24>), a.grid_table, 256, 0, stream, a);
+    else if (a.e_dim <= 32)
+        MAGIC_LAUNCH("gat_bwd_table_partial", (k_bwd_table_partial<H, 32>), a.grid_table, 256, 0, stream, a);
+    else
+        return MAGIC_ERR_UNSUPPORTED;
+    MAGIC_LAUNCH("gat_bwd_table_final", k_bwd_table_final, 1, 256, 0, stream, a, H);
+    return MAGIC_OK;
+}
+
+template <int H, int LPH>
+int launch_bwd(BwdArgs &a, hipStream_t stream) {
+    constexpr int C = H * LPH * 4;
+    MAGIC_LAUNCH("gat_bwd_dst_light", (k_bwd_dst_light<H, LPH>), a.grid_light, 256, 0, stream, a);
+    if (a.d_bias || a.d_prelu) MAGIC_LAUNCH("gat_bwd_reduce_bias", k_bwd_reduce_bias, C + 1, 256, 0, stream, a, C);
+    if (a.pin.n_chunks > 0) {
+        int cgrid = (a.pin.n_chunks + 3) / 4;
+        MAGIC_LAUNCH("gat_bwd_dst_heavy1", (k_bwd_dst_heavy1<H, LPH>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH("gat_bwd_dst_heavy2", (k_bwd_dst_heavy2<H>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH("gat_bwd_dst_heavy3", (k_bwd_dst_heavy3<H>), (a.pin.n_heavy + 3) / 4, 256, 0, stream, a, C);
+    }
+    {
+        constexpr int NPB = 256 / (H * LPH);
+        int grid = stride_grid(a.N, NPB, 256 * 16);
+        MAGIC_LAUNCH("gat_bwd_src_light", (k_bwd_src_light<H, LPH>), grid, 256, 0, stream, a);
+    }
+    if (a.pout.n_chunks > 0) {
+        int cgrid = (a.pout.n_chunks + 3) / 4;
+        MAGIC_LAUNCH("gat_bwd_src_heavy1", (k_bwd_src_heavy1<H, LPH>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH("gat_bwd_src_heavy2", (k_bwd_src_heavy2<H, LPH>), a.pout.n_heavy, 256, 0, stream, a);
+    }
+    int st = launch_table<H>(a, stream);
+    if (st != MAGIC_OK) return st;
+    return launch_status();
+}
+
+static int light_grid(int N, int H, int D) {
+    int npb = 256 / (H * D / 4);
+    return stride_grid(N, npb, 2048);
+}
+static int table_grid(int E) { return stride_grid(E, 256 * 8, 1024); }
+
+}  // namespace magic
+
+extern "C" {
+
+size_t magic_gat_bwd_workspace_bytes(int32_t N, int32_t E, int32_t n_chunks_in, int32_t n_chunks_out, int32_t H,
+                                     int32_t D, int32_t e_dim) {
+    using namespace magic;
+    if (N <= 0 || H <= 0 || D <= 0) return 256;
+    const size_t C = (size_t)H * D, f = sizeof(float);
+    size_t gl = light_grid(N, H, D), gt = table_grid(E);
+    size_t b = align_up(gl * C * f) + align_up(gl * f);
+    b += 2 * align_up((size_t)(n_chunks_in > 0 ? n_chunks_in : 1) * H * f);
+    b += align_up((size_t)(n_chunks_out > 0 ? n_chunks_out : 1) * C * f) +
+         align_up((size_t)(n_chunks_out > 0 ? n_chunks_out : 1) * H * f);
+    b += align_up(gt * (size_t)(e_dim > 0 ? e_dim : 1) * H * f);
+    return b + 256;
+}
+
+int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_src,
+                  const magic_plan *out_plan, const int32_t *out_dst, const int32_t *out_pos, const float *hs,
+                  int64_t ld_hs, const float *attn, const int32_t *etype_csc, int32_t e_dim, float slope,
+                  const float *pre, const float *prelu_w, const float *d_out, int64_t ld_dout, float *d_pre,
+                  int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table, float *edge_rec, float *d_bias, float *d_prelu_w,
+                  void *workspace, size_t workspace_bytes, void *stream_) {
+    using namespace magic;
+    if (N < 0 || E < 0 || H <= 0 || D <= 0) return MAGIC_ERR_INVALID_ARG;
+    if (!shape_supported(H, D)) return MAGIC_ERR_UNSUPPORTED;
+    if (N == 0) return MAGIC_OK;
+    const int C = H * D;
+    if (!plan_valid(in_plan) || !plan_valid(out_plan) || !hs || !d_out || !d_pre || !d_y) return MAGIC_ERR_INVALID_ARG;
+    if (E > 0 && (!in_src || !out_dst || !out_pos || !attn || !edge_rec)) return MAGIC_ERR_INVALID_ARG;
+    if (prelu_w && !pre) return MAGIC_ERR_INVALID_ARG;
+    if (ld_hs < C || ld_dout < C || ld_dy < C + 2 * H || ld_dpre < C) return MAGIC_ERR_INVALID_ARG;
+    if ((ld_hs | ld_dout | ld_dy | ld_dpre) & 3) return MAGIC_ERR_INVALID_ARG;
+    if (etype_csc && d_ee_table && (e_dim <= 0 || e_dim > 32)) return MAGIC_ERR_UNSUPPORTED;
+    BwdArgs a;
+    a.N = N;
+    a.E = E;
+    a.pin = plan_dev(in_plan);
+    a.pout = plan_dev(out_plan);
+    a.in_src = in_src;
+    a.out_dst = out_dst;
+    a.out_pos = out_pos;
+    a.hs = hs;
+    a.ld_hs = ld_hs;
+    a.attn = attn;
+    a.etype = etype_csc;
+    a.e_dim = e_dim;
+    a.slope = slope;
+    a.pre = pre;
+    a.prelu_w = prelu_w;
+    a.d_out = d_out;
+    a.ld_dout = ld_dout;
+    a.d_pre = d_pre;
+    a.ld_dpre = ld_dpre;
+    a.d_y = d_y;
+    a.ld_dy = ld_dy;
+    a.d_table = d_ee_table;
+    a.rec = edge_rec;
+    a.d_bias = d_bias;
+    a.d_prelu = d_prelu_w;
+    a.grid_light = light_grid(N, H, D);
+    a.grid_table = table_grid(E);
+    Arena ar(workspace, workspace_bytes);
+    a.ws_bias = ar.take<float>((size_t)a.grid_light * C);
+    a.ws_prelu = ar.take<float>((size_t)a.grid_light);
+    a.ws_delta = ar.take<float>((size_t)(a.pin.n_chunks > 0 ? a.pin.n_chunks : 1) * H);
+    a.ws_det = ar.take<float>((size_t)(a.pin.n_chunks > 0 ? a.pin.n_chunks : 1) * H);
+    a.ws_acc = ar.take<float>((size_t)(a.pout.n_chunks > 0 ? a.pout.n_chunks : 1) * C);
+    a.ws_deh = ar.take<float>((size_t)(a.pout.n_chunks > 0 ? a.pout.n_chunks : 1) * H);
+    a.ws_table = ar.take<float>((size_t)a.grid_table * (e_dim > 0 ? e_dim : 1) * H);
+    if (!ar.ok()) return MAGIC_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int lph = D / 4;
+#define X(h, l) \
+    if (H == h && lph == l) return launch_bwd<h, l>(a, stream);
+    MAGIC_GAT_SHAPES(X)
+#undef X
+    return MAGIC_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+// Device helpers shared by the GAT forward / backward kernels.
+//
+// Thread mapping used everywhere: a node's H*D channels are spread over G = H*LPH lanes,
+// 4 consecutive channels (one float4) per lane, LPH = D/4 lanes per head.  G is a power of
+// two <= 64, so 64/G nodes (light kernels) or 64/G edge sub-streams (heavy kernels) share
+// one wavefront.
+#pragma once
+#include "common.h"
+#include <math.h>
+
+namespace magic {
+
+struct PlanDev {
+    const int32_t *ptr;
+    int32_t light_max;
+    int32_t n_heavy;
+    const int32_t *heavy_node;
+    const int32_t *heavy_cptr;
+    int32_t n_chunks;
+    const int32_t *chunk_node;
+    const int32_t *chunk_beg;
+    const int32_t *chunk_end;
+};
+
+inline PlanDev plan_dev(const magic_plan *p) {
+    PlanDev d;
+    d.ptr = p->ptr;
+    d.light_max = p->light_max;
+    d.n_heavy = p->n_heavy;
+    d.heavy_node = p->heavy_node;
+    d.heavy_cptr = p->heavy_cptr;
+    d.n_chunks = p->n_chunks;
+    d.chunk_node = p->chunk_node;
+    d.chunk_beg = p->chunk_beg;
+    d.chunk_end = p->chunk_end;
+    return d;
+}
+
+inline bool plan_valid(const magic_plan *p) {
+    if (!p || !p->ptr || p->light_max < 0 || p->n_heavy < 0 || p->n_chunks < 0) return false;
+    if (p->n_heavy > 0 && (!p->heavy_node || !p->heavy_cptr)) return false;
+    if (p->n_chunks > 0 && (!p->chunk_node || !p->chunk_beg || !p->chunk_end)) return false;
+    if ((p->n_heavy == 0) != (p->n_chunks == 0)) return false;
+    return true;
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void fma4(float4 &acc, float a, float4 r) {
+    acc.x = fmaf(a, r.x, acc.x);
+    acc.y = fmaf(a, r.y, acc.y);
+    acc.z = fmaf(a, r.z, acc.z);
+    acc.w = fmaf(a, r.w, acc.w);
+}
+__device__ __forceinline__ void add4(float4 &acc, float4 r) {
+    acc.x += r.x;
+    acc.y += r.y;
+    acc.z += r.z;
+    acc.w += r.w;
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) {
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+
+// sum over the LPH lanes of one head; every lane of the head receives the total
+template <int LPH> __device__ __forceinline__ float head_sum(float v) {
+#pragma unroll
+    for (int off = 1; off < LPH; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// sum over the 64/G sub-streams of a wave (lanes that differ in bits >= log2 G)
+template <int G> __device__ __forceinline__ float substream_sum(float v) {
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int G> __device__ __forceinline__ float4 substream_sum4(float4 v) {
+    v.x = substream_sum<G>(v.x);
+    v.y = substream_sum<G>(v.y);
+    v.z = substream_sum<G>(v.z);
+    v.w = substream_sum<G>(v.w);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// running (max, sum of exp) pairs: fold (m2, s2) into (m, s)
+__device__ __forceinline__ void ms_fold(float &m, float &s, float m2, float s2) {
+    float mn = fmaxf(m, m2);
+    float f1 = (m == -INFINITY) ? 0.f : expf(m - mn);
+    float f2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+    s = s * f1 + s2 * f2;
+    m = mn;
+}
+
+__device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+// attention weight with the sign bit carrying "pre-activation logit was not positive"
+__device__ __forceinline__ float pack_attn(float a, float x) {
+    return x > 0.f ? a : __uint_as_float(__float_as_uint(a) | 0x80000000u);
+}
+__device__ __forceinline__ bool attn_neg(float packed) { return (__float_as_uint(packed) >> 31) != 0u; }
+
+// dispatch over the compiled (H, LPH) shapes
+#define MAGIC_GAT_SHAPES(X) \
+    X(4, 4)                 \
+    X(4, 16)                \
+    X(4, 8)                 \
+    X(4, 2)                 \
+    X(1, 1)                 \
+    X(1, 2)                 \
+    X(1, 4)
+
+inline bool shape_supported(int H, int D) {
+    if (D % 4) return false;
+    int lph = D / 4;
+#define X(h, l) \
+    if (H == h && lph == l) return true;
+    MAGIC_GAT_SHAPES(X)
+#undef X
+    return false;
+}
+
+}  // namespace magic

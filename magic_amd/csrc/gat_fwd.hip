@@ -1,0 +1,332 @@
+// GAT layer, edge phase, forward: attention logits -> leaky ReLU -> per-destination
+// softmax -> weighted aggregation of source rows -> bias + residual (+ PReLU).
+// HBM-bound: per edge one gathered hs row (4*H*D bytes) dominates; everything else is
+// streamed once in CSC order.  No atomics; every reduction has a fixed order.
+#include "gat_common.h"
+
+namespace magic {
+
+struct FwdArgs {
+    int N, E;
+    PlanDev plan;
+    const int32_t *src;  // [E] CSC order
+    const float *hs;
+    int64_t ld_hs;
+    const float *eh;  // [N,ld_s] head scores of the node as a source
+    const float *et;  // [N,ld_s] head scores of the node as a destination
+    int64_t ld_s;
+    const float *ee_table;  // [e_dim,H]
+    const int32_t *etype;   // [E] CSC order
+    const float *ee;        // [E,H] CSC order
+    float slope;
+    const float *bias;
+    const float *res;
+    int64_t ld_res;
+    const float *prelu_w;
+    float *out;
+    int64_t ld_out;
+    float *pre;   // [N,C] or null
+    float *attn;  // [E,H]
+    float *ws_stats;  // [n_chunks,H,2]
+    float *ws_acc;    // [n_chunks,C]
+};
+
+template <int H, bool TABLE>
+__device__ __forceinline__ float raw_logit(const FwdArgs &a, int i, int u, int h, float etv) {
+    float ee = TABLE ? a.ee_table[a.etype[i] * H + h] : a.ee[(int64_t)i * H + h];
+    return (a.eh[(int64_t)u * a.ld_s + h] + ee) + etv;
+}
+
+template <int H, int LPH>
+__device__ __forceinline__ void epilogue(const FwdArgs &a, int v, int g, float4 acc) {
+    constexpr int C = H * LPH * 4;
+    if (a.bias) add4(acc, ld4(a.bias + g * 4));
+    if (a.res) add4(acc, ld4(a.res + (int64_t)v * a.ld_res + g * 4));
+    if (a.pre) st4(a.pre + (int64_t)v * C + g * 4, acc);
+    if (a.prelu_w) {
+        float w = a.prelu_w[0];
+        acc.x = acc.x >= 0.f ? acc.x : w * acc.x;
+        acc.y = acc.y >= 0.f ? acc.y : w * acc.y;
+        acc.z = acc.z >= 0.f ? acc.z : w * acc.z;
+        acc.w = acc.w >= 0.f ? acc.w : w * acc.w;
+    }
+    st4(a.out + (int64_t)v * a.ld_out + g * 4, acc);
+}
+
+// One lane group (G lanes) per destination node; segments longer than light_max are left
+// to the heavy kernels.  Three sweeps over the segment: max, sum of exp, aggregation; the
+// first two touch only the H-float score rows (cache resident), the third gathers hs rows.
+template <int H, int LPH, bool TABLE>
+__global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
+    constexpr int G = H * LPH;
+    constexpr int NPB = 256 / G;
+    const int g = threadIdx.x % G;
+    const int h = g / LPH;
+    const int slot = threadIdx.x / G;
+    const bool writer = (g % LPH) == 0;
+    for (int v = blockIdx.x * NPB + slot; v < a.N; v += gridDim.x * NPB) {
+        const int b = a.plan.ptr[v], e = a.plan.ptr[v + 1];
+        if (e - b > a.plan.light_max) continue;
+        const float etv = a.et[(int64_t)v * a.ld_s + h];
+        float m = -INFINITY;
+        for (int i = b; i < e; ++i) m = fmaxf(m, leaky(raw_logit<H, TABLE>(a, i, a.src[i], h, etv), a.slope));
+        float s = 0.f;
+        for (int i = b; i < e; ++i) s += expf(leaky(raw_logit<H, TABLE>(a, i, a.src[i], h, etv), a.slope) - m);
+        const float inv = 1.f / s;
+        float4 acc = f4zero();
+        int i = b;
+        for (; i + 4 <= e; i += 4) {
+            int u[4];
+            float w[4];
+            float4 r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = a.src[i + j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)u[j] * a.ld_hs + g * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = raw_logit<H, TABLE>(a, i + j, u[j], h, etv);
+                w[j] = expf(leaky(x, a.slope) - m) * inv;
+                if (writer) a.attn[(int64_t)(i + j) * H + h] = pack_attn(w[j], x);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fma4(acc, w[j], r[j]);
+        }
+        for (; i < e; ++i) {
+            int u = a.src[i];
+            float4 r = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
+            float x = raw_logit<H, TABLE>(a, i, u, h, etv);
+            float w = expf(leaky(x, a.slope) - m) * inv;
+            if (writer) a.attn[(int64_t)i * H + h] = pack_attn(w, x);
+            fma4(acc, w, r);
+        }
+        epilogue<H, LPH>(a, v, g, acc);
+    }
+}
+
+// Heavy segments, step 1: one wave per chunk, one lane per edge; per-chunk (max, sum exp)
+// for every head.
+template <int H, bool TABLE>
+__global__ __launch_bounds__(256) void k_fwd_heavy_stats(FwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= a.plan.n_chunks) return;
+    const int v = a.plan.heavy_node[a.plan.chunk_node[c]];
+    const int beg = a.plan.chunk_beg[c], end = a.plan.chunk_end[c];
+    float m[H], s[H], etv[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        m[h] = -INFINITY;
+        s[h] = 0.f;
+        etv[h] = a.et[(int64_t)v * a.ld_s + h];
+    }
+    for (int i = beg + lane; i < end; i += 64) {
+        const int u = a.src[i];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float l = leaky(raw_logit<H, TABLE>(a, i, u, h, etv[h]), a.slope);
+            ms_fold(m[h], s[h], l, 1.f);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            float m2 = __shfl_xor(m[h], off, 64), s2 = __shfl_xor(s[h], off, 64);
+            ms_fold(m[h], s[h], m2, s2);
+        }
+        if (lane == 0) {
+            a.ws_stats[((int64_t)c * H + h) * 2 + 0] = m[h];
+            a.ws_stats[((int64_t)c * H + h) * 2 + 1] = s[h];
+        }
+    }
+}
+
+// Fold the per-chunk statistics of heavy node `slot` in chunk order (lanes take chunks
+// round robin, then a fixed butterfly); every lane ends with the node's (max, sum).
+template <int H>
+__device__ __forceinline__ void node_stats(const FwdArgs &a, int slot, int lane, float (&m)[H], float (&s)[H]) {
+    const int c0 = a.plan.heavy_cptr[slot], c1 = a.plan.heavy_cptr[slot + 1];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        m[h] = -INFINITY;
+        s[h] = 0.f;
+    }
+    for (int c = c0 + lane; c < c1; c += 64) {
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+            ms_fold(m[h], s[h], a.ws_stats[((int64_t)c * H + h) * 2], a.ws_stats[((int64_t)c * H + h) * 2 + 1]);
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            float m2 = __shfl_xor(m[h], off, 64), s2 = __shfl_xor(s[h], off, 64);
+            ms_fold(m[h], s[h], m2, s2);
+        }
+    }
+}
+
+// Heavy segments, step 2: one wave per chunk; the 64/G lane groups take edges round robin,
+// write the attention weights and a partial aggregate per chunk.
+template <int H, int LPH, bool TABLE>
+__global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
+    constexpr int G = H * LPH;
+    constexpr int NSG = 64 / G;
+    constexpr int C = G * 4;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= a.plan.n_chunks) return;
+    const int slot = a.plan.chunk_node[c];
+    const int v = a.plan.heavy_node[slot];
+    const int beg = a.plan.chunk_beg[c], end = a.plan.chunk_end[c];
+    float mm[H], ss[H];
+    node_stats<H>(a, slot, lane, mm, ss);
+    const int g = lane % G, sg = lane / G, h = g / LPH;
+    float m = mm[0], s = ss[0];
+#pragma unroll
+    for (int k = 1; k < H; ++k)
+        if (h == k) {
+            m = mm[k];
+            s = ss[k];
+        }
+    const float inv = 1.f / s;
+    const float etv = a.et[(int64_t)v * a.ld_s + h];
+    const bool writer = (g % LPH) == 0;
+    float4 acc = f4zero();
+    int i = beg + sg;
+    for (; i + 3 * NSG < end; i += 4 * NSG) {
+        int u[4];
+        float4 r[4];
+        float w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = a.src[i + j * NSG];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)u[j] * a.ld_hs + g * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = raw_logit<H, TABLE>(a, i + j * NSG, u[j], h, etv);
+            w[j] = expf(leaky(x, a.slope) - m) * inv;
+            if (writer) a.attn[(int64_t)(i + j * NSG) * H + h] = pack_attn(w[j], x);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fma4(acc, w[j], r[j]);
+    }
+    for (; i < end; i += NSG) {
+        int u = a.src[i];
+        float4 r = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
+        float x = raw_logit<H, TABLE>(a, i, u, h, etv);
+        float w = expf(leaky(x, a.slope) - m) * inv;
+        if (writer) a.attn[(int64_t)i * H + h] = pack_attn(w, x);
+        fma4(acc, w, r);
+    }
+    acc = substream_sum4<G>(acc);
+    if (sg == 0) st4(a.ws_acc + (int64_t)c * C + g * 4, acc);
+}
+
+// Heavy segments, step 3: one block per heavy node sums its chunk partials in a fixed order
+// (sub-groups take chunks round robin, LDS tree in sub-group order) and applies the epilogue.
+template <int H, int LPH>
+__global__ __launch_bounds__(256) void k_fwd_heavy_finish(FwdArgs a) {
+    constexpr int G = H * LPH;
+    constexpr int NSGB = 256 / G;
+    constexpr int C = G * 4;
+    __shared__ float4 part[256];
+    const int slot = blockIdx.x;
+    const int g = threadIdx.x % G, sg = threadIdx.x / G;
+    const int c0 = a.plan.heavy_cptr[slot], c1 = a.plan.heavy_cptr[slot + 1];
+    float4 acc = f4zero();
+    for (int c = c0 + sg; c < c1; c += NSGB) add4(acc, ld4(a.ws_acc + (int64_t)c * C + g * 4));
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (sg == 0) {
+        for (int k = 1; k < NSGB; ++k) add4(acc, part[k * G + g]);
+        epilogue<H, LPH>(a, a.plan.heavy_node[slot], g, acc);
+    }
+}
+
+template <int H, int LPH, bool TABLE>
+int launch_fwd(const FwdArgs &a, hipStream_t stream) {
+    constexpr int G = H * LPH;
+    constexpr int NPB = 256 / G;
+    if (a.N > 0) {
+        int grid = stride_grid(a.N, NPB, 256 * 16);
+        MAGIC_LAUNCH("gat_fwd_light", (k_fwd_light<H, LPH, TABLE>), grid, 256, 0, stream, a);
+    }
+    if (a.plan.n_chunks > 0) {
+        int cgrid = (a.plan.n_chunks + 3) / 4;
+        MAGIC_LAUNCH("gat_fwd_heavy_stats", (k_fwd_heavy_stats<H, TABLE>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH("gat_fwd_heavy_agg", (k_fwd_heavy_agg<H, LPH, TABLE>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH("gat_fwd_heavy_finish", (k_fwd_heavy_finish<H, LPH>), a.plan.n_heavy, 256, 0, stream, a);
+    }
+    return launch_status();
+}
+
+}  // namespace magic
+
+extern "C" {
+
+size_t magic_gat_fwd_workspace_bytes(int32_t n_chunks, int32_t H, int32_t D) {
+    if (n_chunks <= 0) return 256;
+    return magic::align_up((size_t)n_chunks * H * 2 * sizeof(float)) +
+           magic::align_up((size_t)n_chunks * H * D * sizeof(float)) + 256;
+}
+
+int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_src,
+                  const float *hs, int64_t ld_hs, const float *eh, const float *et, int64_t ld_score,
+                  const float *ee_table,
+                  const int32_t *etype_csc, const float *ee_csc, float slope, const float *bias,
+                  const float *res, int64_t ld_res, const float *prelu_w, float *out, int64_t ld_out,
+                  float *pre, float *attn, void *workspace, size_t workspace_bytes, void *stream_) {
+    using namespace magic;
+    if (N < 0 || E < 0 || H <= 0 || D <= 0) return MAGIC_ERR_INVALID_ARG;
+    if (!shape_supported(H, D)) return MAGIC_ERR_UNSUPPORTED;
+    if (N == 0) return MAGIC_OK;
+    if (!plan_valid(in_plan) || !hs || !eh || !et || !out) return MAGIC_ERR_INVALID_ARG;
+    if (E > 0 && (!in_src || !attn)) return MAGIC_ERR_INVALID_ARG;
+    const bool table = ee_table != nullptr;
+    if (E > 0 && table && !etype_csc) return MAGIC_ERR_INVALID_ARG;
+    if (E > 0 && !table && !ee_csc) return MAGIC_ERR_INVALID_ARG;
+    const int C = H * D;
+    if (ld_hs < C || ld_out < C || (res && ld_res < C) || ld_score < H) return MAGIC_ERR_INVALID_ARG;
+    if ((ld_hs | ld_out | (res ? ld_res : 0)) & 3) return MAGIC_ERR_INVALID_ARG;  // float4 rows
+    FwdArgs a;
+    a.N = N;
+    a.E = E;
+    a.plan = plan_dev(in_plan);
+    a.src = in_src;
+    a.hs = hs;
+    a.ld_hs = ld_hs;
+    a.eh = eh;
+    a.et = et;
+    a.ld_s = ld_score;
+    a.ee_table = ee_table;
+    a.etype = etype_csc;
+    a.ee = ee_csc;
+    a.slope = slope;
+    a.bias = bias;
+    a.res = res;
+    a.ld_res = ld_res;
+    a.prelu_w = prelu_w;
+    a.out = out;
+    a.ld_out = ld_out;
+    a.pre = pre;
+    a.attn = attn;
+    a.ws_stats = a.ws_acc = nullptr;
+    if (a.plan.n_chunks > 0) {
+        Arena ar(workspace, workspace_bytes);
+        a.ws_stats = ar.take<float>((size_t)a.plan.n_chunks * H * 2);
+        a.ws_acc = ar.take<float>((size_t)a.plan.n_chunks * C);
+        if (!ar.ok() || !a.ws_stats || !a.ws_acc) return MAGIC_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const int lph = D / 4;
+#define X(h, l)                                                              \
+    if (H == h && lph == l)                                                  \
+        return table ? launch_fwd<h, l, true>(a, stream) : launch_fwd<h, l, false>(a, stream);
+    MAGIC_GAT_SHAPES(X)
+#undef X
+    return MAGIC_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

@@ -1,0 +1,478 @@
+// Brute-force k-nearest-neighbour search in float64 on the f64 matrix cores.
+//
+// key(q, t) = |t|^2 - 2 q.t  orders the train rows of one query exactly like the squared
+// Euclidean distance does (|q|^2 is constant per query and added at the end).  The q.t
+// products come from v_mfma_f64_16x16x4_f64 with float32 inputs widened in registers (a
+// float32 x float32 product is exact in float64).  Each lane keeps the current k-th best
+// key of "its" query and only candidates below it enter a sorted list (in LDS for small k,
+// in global memory otherwise); after the first few tiles insertions are rare
+// (~k ln(N/k) per query), so the kernel runs at the matrix-core rate.
+//
+// MFMA f64 16x16x4 operand map (lane l): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// D[i = (l>>4) + 4*reg][j = l&15].  The K dimension is permuted so that lane group (l>>4)
+// owns 16 contiguous input dims: A and B use the same permutation, the sum is unchanged.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int TQ = 256;   // queries per block (4 waves x 4 blocks of 16)
+constexpr int TT = 64;    // train rows per LDS tile
+constexpr int DP = 64;    // padded feature width of the MFMA path
+constexpr int LDT = 68;   // LDS row stride in floats (272 B: 16-B aligned, spreads banks)
+constexpr int kIdxNone = 0x7fffffff;
+
+struct KnnArgs {
+    int64_t n_train, n_query;
+    int d, k;
+    const float *train;
+    int64_t ld_train;
+    const float *query;
+    int64_t ld_query;
+    const double *tnorm;  // [n_train]
+    int n_split;
+    int64_t rows_per_split;  // multiple of TT
+    double *part_key;        // [n_split, Qpad, k]
+    int *part_idx;           // [n_split, Qpad, k]
+    int64_t q_pad;
+    int lds_lists;
+};
+
+__global__ __launch_bounds__(256) void k_sqnorm(int64_t n, int d, const float *__restrict__ x, int64_t ld,
+                                                double *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i < n; i += (int64_t)gridDim.x * 256) {
+        double s = 0.0;
+        for (int j = 0; j < d; ++j) {
+            double v = (double)x[i * ld + j];
+            s = fma(v, v, s);
+        }
+        out[i] = s;
+    }
+}
+
+// list access: LDS lists are plain; global lists go through L2 (agent scope) so that every
+// lane of the wave sees the wave's earlier insertions
+template <bool GLOBAL> __device__ __forceinline__ double ld_key(const double *p) {
+    if (GLOBAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool GLOBAL> __device__ __forceinline__ int ld_idx(const int *p) {
+    if (GLOBAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool GLOBAL> __device__ __forceinline__ void st_key(double *p, double v) {
+    if (GLOBAL)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+template <bool GLOBAL> __device__ __forceinline__ void st_idx(int *p, int v) {
+    if (GLOBAL)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
+// Whole-wave sorted insertion of (kv, ti) into the k-entry list of one query (wave-uniform
+// arguments).  Order: ascending (key, index).  Returns the new k-th key.
+template <bool GLOBAL>
+__device__ __forceinline__ double wave_insert(double *L, int *I, int k, double kv, int ti, int lane) {
+    int pos = 0;
+    for (int base = 0; base < k; base += 64) {
+        int j = base + lane;
+        bool before = false;
+        if (j < k) {
+            double v = ld_key<GLOBAL>(L + j);
+            int vi = ld_idx<GLOBAL>(I + j);
+            before = (v < kv) || (v == kv && vi < ti);
+        }
+        pos += __popcll(__ballot(before));
+    }
+    if (pos >= k) return ld_key<GLOBAL>(L + k - 1);
+    for (int base = ((k - 1) / 64) * 64; base >= 0; base -= 64) {
+        int j = base + lane;
+        double v = 0.0;
+        int vi = 0;
+        bool mv = j >= pos && j + 1 < k;
+        if (mv) {
+            v = ld_key<GLOBAL>(L + j);
+            vi = ld_idx<GLOBAL>(I + j);
+        }
+        if (GLOBAL) __builtin_amdgcn_s_waitcnt(0);
+        if (mv) {
+            st_key<GLOBAL>(L + j + 1, v);
+            st_idx<GLOBAL>(I + j + 1, vi);
+        }
+        if (GLOBAL) __builtin_amdgcn_s_waitcnt(0);
+    }
+    if (lane == 0) {
+        st_key<GLOBAL>(L + pos, kv);
+        st_idx<GLOBAL>(I + pos, ti);
+    }
+    if (GLOBAL) __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    return ld_key<GLOBAL>(L + k - 1);
+}
+
+template <bool GLOBAL>
+__global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
+    extern __shared__ __align__(16) char smem[];
+    float *tile = reinterpret_cast<float *>(smem);                         // TT*LDT floats
+    double *tn = reinterpret_cast<double *>(smem + TT * LDT * 4);          // TT
+    double *thr = tn + TT;                                                 // TQ
+    double *lkey = thr + TQ;                                               // TQ*k (LDS lists)
+    int *lidx = reinterpret_cast<int *>(lkey + (GLOBAL ? 0 : (size_t)TQ * a.k));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.y;
+    const int64_t q_base = (int64_t)blockIdx.x * TQ;
+    const int64_t t_lo = (int64_t)split * a.rows_per_split;
+    int64_t t_hi = t_lo + a.rows_per_split;
+    if (t_hi > a.n_train) t_hi = a.n_train;
+
+    double *L0;
+    int *I0;
+    if (GLOBAL) {
+        L0 = a.part_key + ((int64_t)split * a.q_pad + q_base) * a.k;
+        I0 = a.part_idx + ((int64_t)split * a.q_pad + q_base) * a.k;
+    } else {
+        L0 = lkey;
+        I0 = lidx;
+    }
+    for (int i = tid; i < TQ * a.k; i += 256) {
+        st_key<GLOBAL>(L0 + i, INFINITY);
+        st_idx<GLOBAL>(I0 + i, kIdxNone);
+    }
+    thr[tid] = INFINITY;
+
+    // query fragments: lane holds dims [16*(lane>>4), +16) of query (wave*64 + qb*16 + lane&15)
+    double bq[4][16];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+        int64_t q = q_base + wave * 64 + qb * 16 + (lane & 15);
+        const int d0 = 16 * (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float v = 0.f;
+            if (q < a.n_query && d0 + j < a.d) v = a.query[q * a.ld_query + d0 + j];
+            bq[qb][j] = (double)v;
+        }
+    }
+    __syncthreads();
+
+    for (int64_t t0 = t_lo; t0 < t_hi; t0 += TT) {
+        // stage TT train rows (zero padded) + their squared norms
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TT / 16; ++i) {
+            int r = (tid >> 4) + 16 * i;
+            int c4 = (tid & 15) * 4;
+            int64_t row = t0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < t_hi) {
+                const float *p = a.train + row * a.ld_train + c4;
+                if (c4 + 3 < a.d) {
+                    v = *reinterpret_cast<const float4 *>(p);
+                } else {
+                    if (c4 + 0 < a.d) v.x = p[0];
+                    if (c4 + 1 < a.d) v.y = p[1];
+                    if (c4 + 2 < a.d) v.z = p[2];
+                }
+            }
+            *reinterpret_cast<float4 *>(tile + r * LDT + c4) = v;
+        }
+        if (tid < TT) tn[tid] = (t0 + tid < t_hi) ? a.tnorm[t0 + tid] : (double)INFINITY;
+        __syncthreads();
+
+#pragma unroll 1
+        for (int tb = 0; tb < TT / 16; ++tb) {
+            double af[16];
+            {
+                const float *p = tile + (tb * 16 + (lane & 15)) * LDT + 16 * (lane >> 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 v = *reinterpret_cast<const float4 *>(p + 4 * j);
+                    af[4 * j + 0] = (double)v.x;
+                    af[4 * j + 1] = (double)v.y;
+                    af[4 * j + 2] = (double)v.z;
+                    af[4 * j + 3] = (double)v.w;
+                }
+            }
+            double tnr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tnr[r] = tn[tb * 16 + (lane >> 4) + 4 * r];
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) {
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bq[qb][ks], acc, 0, 0, 0);
+                const int ql = wave * 64 + qb * 16 + (lane & 15);
+                const double th = thr[ql];
+                double key[4];
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    key[r] = fma(-2.0, acc[r], tnr[r]);
+                    any |= key[r] < th;
+                }
+                if (__any(any)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        unsigned long long mask = __ballot(key[r] < th);
+                        const int ti_mine = (int)(t0 + tb * 16 + (lane >> 4) + 4 * r);
+                        while (mask) {
+                            const int srcl = __ffsll((long long)mask) - 1;
+                            mask &= mask - 1;
+                            const int q_ins = __shfl(ql, srcl, 64);
+                            const double kv = __shfl(key[r], srcl, 64);
+                            const int ti = __shfl(ti_mine, srcl, 64);
+                            if (kv < thr[q_ins]) {
+                                double nt = wave_insert<GLOBAL>(L0 + (int64_t)q_ins * a.k, I0 + (int64_t)q_ins * a.k,
+                                                                a.k, kv, ti, lane);
+                                if (lane == 0) thr[q_ins] = nt;
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!GLOBAL) {
+        __syncthreads();
+        double *gk = a.part_key + ((int64_t)split * a.q_pad + q_base) * a.k;
+        int *gi = a.part_idx + ((int64_t)split * a.q_pad + q_base) * a.k;
+        for (int i = tid; i < TQ * a.k; i += 256) {
+            gk[i] = lkey[i];
+            gi[i] = lidx[i];
+        }
+    }
+}
+
+// merge the per-split lists of one query, add |q|^2, sqrt, apply the index offset
+__global__ __launch_bounds__(256) void k_knn_finalize(KnnArgs a, int64_t index_offset, double *dist, int64_t *idx) {
+    int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.n_query) return;
+    double qn = 0.0;
+    for (int j = 0; j < a.d; ++j) {
+        double v = (double)a.query[q * a.ld_query + j];
+        qn = fma(v, v, qn);
+    }
+    // heads of the n_split sorted lists live in registers only for small n_split; use a
+    // simple cursor array in local memory otherwise (n_split <= 64)
+    int cur[64];
+    for (int s = 0; s < a.n_split; ++s) cur[s] = 0;
+    for (int o = 0; o < a.k; ++o) {
+        double best = INFINITY;
+        int bi = kIdxNone, bs = -1;
+        for (int s = 0; s < a.n_split; ++s) {
+            if (cur[s] >= a.k) continue;
+            int64_t off = ((int64_t)s * a.q_pad + q) * a.k + cur[s];
+            double v = a.part_key[off];
+            int vi = a.part_idx[off];
+            if (v < best || (v == best && vi < bi)) {
+                best = v;
+                bi = vi;
+                bs = s;
+            }
+        }
+        if (bs >= 0) cur[bs]++;
+        double d2 = best + qn;
+        dist[q * a.k + o] = bs >= 0 && bi != kIdxNone ? sqrt(d2 > 0.0 ? d2 : 0.0) : (double)INFINITY;
+        idx[q * a.k + o] = bs >= 0 && bi != kIdxNone ? (int64_t)bi + index_offset : (int64_t)-1;
+    }
+}
+
+// ---- generic path (any feature width, small problems): exact float64 keys, one block per
+// query, k rounds of block-wide arg-min in (key, index) order -------------------------------
+__global__ __launch_bounds__(256) void k_knn_generic(KnnArgs a, int64_t index_offset, double *keys /* [Q,N] */,
+                                                     double *dist, int64_t *idx) {
+    __shared__ double rk[4];
+    __shared__ int ri[4];
+    const int64_t q = blockIdx.x;
+    const float *qr = a.query + q * a.ld_query;
+    double qn = 0.0;
+    for (int j = 0; j < a.d; ++j) qn = fma((double)qr[j], (double)qr[j], qn);
+    double *row = keys + q * a.n_train;
+    for (int64_t t = threadIdx.x; t < a.n_train; t += 256) {
+        const float *tr = a.train + t * a.ld_train;
+        double dot = 0.0;
+        for (int j = 0; j < a.d; ++j) dot = fma((double)qr[j], (double)tr[j], dot);
+        row[t] = fma(-2.0, dot, a.tnorm[t]);
+    }
+    __syncthreads();
+    for (int o = 0; o < a.k; ++o) {
+        double best = INFINITY;
+        int bi = kIdxNone;
+        for (int64_t t = threadIdx.x; t < a.n_train; t += 256) {
+            double v = row[t];
+            if (v < best || (v == best && (int)t < bi)) {
+                best = v;
+                bi = (int)t;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            double ov = __shfl_xor(best, off, 64);
+            int oi = __shfl_xor(bi, off, 64);
+            if (ov < best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        if ((threadIdx.x & 63) == 0) {
+            rk[threadIdx.x >> 6] = best;
+            ri[threadIdx.x >> 6] = bi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (rk[w] < best || (rk[w] == best && ri[w] < bi)) {
+                    best = rk[w];
+                    bi = ri[w];
+                }
+            if (bi != kIdxNone) {
+                double d2 = best + qn;
+                dist[q * a.k + o] = sqrt(d2 > 0.0 ? d2 : 0.0);
+                idx[q * a.k + o] = (int64_t)bi + index_offset;
+                row[bi] = INFINITY;  // taken
+            } else {
+                dist[q * a.k + o] = INFINITY;
+                idx[q * a.k + o] = -1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_knn_merge(int64_t n_query, int k, int n_parts, const double *pd,
+                                                   const int64_t *pi, double *dist, int64_t *idx) {
+    int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_query) return;
+    int cur[64];
+    for (int s = 0; s < n_parts; ++s) cur[s] = 0;
+    for (int o = 0; o < k; ++o) {
+        double best = INFINITY;
+        int64_t bi = INT64_MAX;
+        int bs = -1;
+        for (int s = 0; s < n_parts; ++s) {
+            if (cur[s] >= k) continue;
+            int64_t off = ((int64_t)s * n_query + q) * k + cur[s];
+            double v = pd[off];
+            int64_t vi = pi[off];
+            if (vi < 0) continue;
+            if (bs < 0 || v < best || (v == best && vi < bi)) {
+                best = v;
+                bi = vi;
+                bs = s;
+            }
+        }
+        if (bs >= 0) cur[bs]++;
+        dist[q * k + o] = bs >= 0 ? best : (double)INFINITY;
+        idx[q * k + o] = bs >= 0 ? bi : (int64_t)-1;
+    }
+}
+
+bool mfma_path(int d) { return d >= 1 && d <= DP; }
+
+void plan_split(int64_t n_train, int64_t n_query, int *n_split, int64_t *rows_per_split) {
+    int64_t qblocks = (n_query + TQ - 1) / TQ;
+    int64_t tiles = (n_train + TT - 1) / TT;
+    int64_t s = 1;
+    if (qblocks < 512) s = (512 + qblocks - 1) / qblocks;
+    if (s > 64) s = 64;
+    int64_t max_s = tiles / 8 > 0 ? tiles / 8 : 1;  // at least 8 tiles per split
+    if (s > max_s) s = max_s;
+    int64_t tps = (tiles + s - 1) / s;
+    s = (tiles + tps - 1) / tps;
+    *n_split = (int)s;
+    *rows_per_split = tps * TT;
+}
+
+size_t lds_bytes(int k, bool lds_lists) {
+    return (size_t)TT * LDT * 4 + (size_t)TT * 8 + (size_t)TQ * 8 + (lds_lists ? (size_t)TQ * k * 12 : 0);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t magic_knn_workspace_bytes(int64_t n_train, int64_t n_query, int32_t d, int32_t k) {
+    if (n_train <= 0 || n_query <= 0 || d <= 0 || k <= 0) return 256;
+    size_t b = magic::align_up((size_t)n_train * 8);
+    if (mfma_path(d)) {
+        int ns;
+        int64_t rps;
+        plan_split(n_train, n_query, &ns, &rps);
+        size_t qpad = (size_t)((n_query + TQ - 1) / TQ) * TQ;
+        b += magic::align_up((size_t)ns * qpad * k * 8) + magic::align_up((size_t)ns * qpad * k * 4);
+    } else {
+        b += magic::align_up((size_t)n_query * (size_t)n_train * 8);  // generic path key matrix
+    }
+    return b + 256;
+}
+
+int magic_knn_topk(int64_t n_train, int64_t n_query, int32_t d, int32_t k, const float *train, int64_t ld_train,
+                   const float *query, int64_t ld_query, int64_t index_offset, double *dist, int64_t *idx,
+                   void *workspace, size_t workspace_bytes, void *stream_) {
+    if (n_train <= 0 || n_query < 0 || d <= 0 || k <= 0 || k > n_train) return MAGIC_ERR_INVALID_ARG;
+    if (n_train >= INT32_MAX) return MAGIC_ERR_UNSUPPORTED;
+    if (n_query == 0) return MAGIC_OK;
+    if (!train || !query || !dist || !idx || ld_train < d || ld_query < d) return MAGIC_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    magic::Arena ar(workspace, workspace_bytes);
+    KnnArgs a;
+    a.n_train = n_train;
+    a.n_query = n_query;
+    a.d = d;
+    a.k = k;
+    a.train = train;
+    a.ld_train = ld_train;
+    a.query = query;
+    a.ld_query = ld_query;
+    double *tnorm = ar.take<double>(n_train);
+    if (!tnorm) return MAGIC_ERR_WORKSPACE;
+    a.tnorm = tnorm;
+    MAGIC_LAUNCH("knn_sqnorm", k_sqnorm, magic::stride_grid(n_train, 256), 256, 0, stream, n_train, d, train, ld_train,
+                 tnorm);
+    if (mfma_path(d)) {
+        if ((ld_train % 4) != 0 || ((uintptr_t)train % 16) != 0) return MAGIC_ERR_INVALID_ARG;  // float4 row loads
+        plan_split(n_train, n_query, &a.n_split, &a.rows_per_split);
+        a.q_pad = (n_query + TQ - 1) / TQ * TQ;
+        a.part_key = ar.take<double>((size_t)a.n_split * a.q_pad * k);
+        a.part_idx = ar.take<int>((size_t)a.n_split * a.q_pad * k);
+        if (!ar.ok() || !a.part_key || !a.part_idx) return MAGIC_ERR_WORKSPACE;
+        a.lds_lists = lds_bytes(k, true) <= 64 * 1024;
+        dim3 grid((unsigned)(a.q_pad / TQ), (unsigned)a.n_split);
+        size_t sh = lds_bytes(k, a.lds_lists);
+        if (a.lds_lists)
+            MAGIC_LAUNCH("knn_topk_f64_mfma", (k_knn_mfma<false>), grid, 256, sh, stream, a);
+        else
+            MAGIC_LAUNCH("knn_topk_f64_mfma", (k_knn_mfma<true>), grid, 256, sh, stream, a);
+        MAGIC_LAUNCH("knn_finalize", k_knn_finalize, (unsigned)((n_query + 255) / 256), 256, 0, stream, a, index_offset,
+                     dist, idx);
+    } else {
+        double *keys = ar.take<double>((size_t)n_query * n_train);
+        if (!ar.ok() || !keys) return MAGIC_ERR_WORKSPACE;
+        MAGIC_LAUNCH("knn_generic_f64", k_knn_generic, (unsigned)n_query, 256, 0, stream, a, index_offset, keys, dist,
+                     idx);
+    }
+    return magic::launch_status();
+}
+
+int magic_knn_merge(int64_t n_query, int32_t k, int32_t n_parts, const double *part_dist, const int64_t *part_idx,
+                    double *dist, int64_t *idx, void *stream_) {
+    if (n_query < 0 || k <= 0 || n_parts <= 0 || n_parts > 64) return MAGIC_ERR_INVALID_ARG;
+    if (n_query == 0) return MAGIC_OK;
+    if (!part_dist || !part_idx || !dist || !idx) return MAGIC_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    MAGIC_LAUNCH("knn_merge", k_knn_merge, (unsigned)((n_query + 255) / 256), 256, 0, stream, n_query, k, n_parts,
+                 part_dist, part_idx, dist, idx);
+    return magic::launch_status();
+}
+
+}  // extern "C"

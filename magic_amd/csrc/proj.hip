@@ -1,0 +1,198 @@
+// Dense node projection  Y = X . W^T  in exact fp32 on the matrix cores
+// (v_mfma_f32_32x32x2_f32: bit-equal to an fmaf chain over k), with the output columns
+// routed to three destinations: the gathered operand hs (kept in its own 128-byte aligned
+// rows), the 2H attention score columns, and the residual projection.
+//
+// Block = 4 waves = 128 input rows x all M output columns; K is walked in chunks of 32
+// staged through LDS.  Operand map of the 32x32x2 MFMA (lane l): A[i = l&31][k = l>>5],
+// B[k = l>>5][j = l&31], D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].  Inside a chunk the
+// K index is permuted so that lane half (l>>5) owns 16 contiguous k: A and B use the same
+// permutation, which only reorders the k-sum.  The kernel is HBM-bound (N*(F+M)*4 bytes
+// against 2*N*F*M flops with F, M <= 264), so the tile is sized for streaming, not reuse.
+#include "common.h"
+
+namespace {
+
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;   // rows per block
+constexpr int KC = 32;    // k per LDS chunk
+constexpr int LDS_LD = 36;  // floats per staged row (144 B)
+
+struct ProjArgs {
+    int64_t n;
+    int F, M, C, NS, RC;
+    const float *x;
+    int64_t ld_x;
+    const float *w;
+    float *hs;
+    int64_t ld_hs;
+    float *score;
+    float *res;
+    int64_t ld_res;
+};
+
+template <int NCT>  // number of 32-column tiles
+__global__ __launch_bounds__(256) void k_proj(ProjArgs a) {
+    extern __shared__ __align__(16) float sm[];
+    float *xs = sm;                  // [BM][LDS_LD]
+    float *ws = sm + BM * LDS_LD;    // [NCT*32][LDS_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hf = lane >> 5, lr = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    float16_t acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    const bool vec = (a.F % 4 == 0) && (a.ld_x % 4 == 0) && ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0);
+
+    for (int k0 = 0; k0 < a.F; k0 += KC) {
+        __syncthreads();
+        // stage X chunk: BM rows x KC floats
+        for (int idx = tid; idx < BM * (KC / 4); idx += 256) {
+            int r = idx / (KC / 4), c4 = (idx % (KC / 4)) * 4;
+            int64_t row = row0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < a.n) {
+                const float *p = a.x + row * a.ld_x + k0 + c4;
+                if (vec && k0 + c4 + 3 < a.F) {
+                    v = *reinterpret_cast<const float4 *>(p);
+                } else {
+                    if (k0 + c4 + 0 < a.F) v.x = p[0];
+                    if (k0 + c4 + 1 < a.F) v.y = p[1];
+                    if (k0 + c4 + 2 < a.F) v.z = p[2];
+                    if (k0 + c4 + 3 < a.F) v.w = p[3];
+                }
+            }
+            *reinterpret_cast<float4 *>(xs + r * LDS_LD + c4) = v;
+        }
+        // stage W chunk: NCT*32 output channels x KC floats
+        for (int idx = tid; idx < NCT * 32 * (KC / 4); idx += 256) {
+            int r = idx / (KC / 4), c4 = (idx % (KC / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < a.M) {
+                const float *p = a.w + (int64_t)r * a.F + k0 + c4;
+                if (vec && k0 + c4 + 3 < a.F) {
+                    v = *reinterpret_cast<const float4 *>(p);
+                } else {
+                    if (k0 + c4 + 0 < a.F) v.x = p[0];
+                    if (k0 + c4 + 1 < a.F) v.y = p[1];
+                    if (k0 + c4 + 2 < a.F) v.z = p[2];
+                    if (k0 + c4 + 3 < a.F) v.w = p[3];
+                }
+            }
+            *reinterpret_cast<float4 *>(ws + r * LDS_LD + c4) = v;
+        }
+        __syncthreads();
+        float af[16];
+        {
+            const float *p = xs + (wave * 32 + lr) * LDS_LD + hf * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 v = *reinterpret_cast<const float4 *>(p + 4 * j);
+                af[4 * j] = v.x;
+                af[4 * j + 1] = v.y;
+                af[4 * j + 2] = v.z;
+                af[4 * j + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            float bf[16];
+            const float *p = ws + (ct * 32 + lr) * LDS_LD + hf * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 v = *reinterpret_cast<const float4 *>(p + 4 * j);
+                bf[4 * j] = v.x;
+                bf[4 * j + 1] = v.y;
+                bf[4 * j + 2] = v.z;
+                bf[4 * j + 3] = v.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc[ct], 0, 0, 0);
+        }
+    }
+    // epilogue: route columns
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int col = ct * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            if (row >= a.n) continue;
+            const float v = acc[ct][r];
+            if (col < a.C) {
+                a.hs[row * a.ld_hs + col] = v;
+            } else if (col < a.C + a.NS) {
+                a.score[row * a.NS + (col - a.C)] = v;
+            } else if (col < a.M) {
+                a.res[row * a.ld_res + (col - a.C - a.NS)] = v;
+            }
+        }
+    }
+}
+
+template <int NCT> int launch(const ProjArgs &a, hipStream_t stream) {
+    size_t sh = (size_t)(BM + NCT * 32) * LDS_LD * sizeof(float);
+    unsigned grid = (unsigned)((a.n + BM - 1) / BM);
+    static bool attr_set = false;
+    if (sh > 48 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_proj<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        attr_set = true;
+    }
+    MAGIC_LAUNCH("proj_fwd_mfma_f32", (k_proj<NCT>), grid, 256, sh, stream, a);
+    return magic::launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_score, int32_t res_c, const float *x,
+                   int64_t ld_x, const float *w, float *hs, int64_t ld_hs, float *score, float *res, int64_t ld_res,
+                   void *stream_) {
+    if (n_rows < 0 || in_dim <= 0 || out_c <= 0 || n_score < 0 || res_c < 0) return MAGIC_ERR_INVALID_ARG;
+    if (n_rows == 0) return MAGIC_OK;
+    if (!x || !w || !hs || ld_x < in_dim || ld_hs < out_c) return MAGIC_ERR_INVALID_ARG;
+    if ((n_score > 0 && !score) || (res_c > 0 && (!res || ld_res < res_c))) return MAGIC_ERR_INVALID_ARG;
+    ProjArgs a;
+    a.n = n_rows;
+    a.F = in_dim;
+    a.C = out_c;
+    a.NS = n_score;
+    a.RC = res_c;
+    a.M = out_c + n_score + res_c;
+    a.x = x;
+    a.ld_x = ld_x;
+    a.w = w;
+    a.hs = hs;
+    a.ld_hs = ld_hs;
+    a.score = score;
+    a.res = res;
+    a.ld_res = ld_res;
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((a.M + 31) / 32 > 10 && res_c > 0) {
+        // too many accumulator tiles for one pass: residual columns in a second pass
+        int st = magic_proj_fwd(n_rows, in_dim, out_c, n_score, 0, x, ld_x, w, hs, ld_hs, score, nullptr, 0, stream_);
+        if (st != MAGIC_OK) return st;
+        return magic_proj_fwd(n_rows, in_dim, res_c, 0, 0, x, ld_x, w + (int64_t)(out_c + n_score) * in_dim, res,
+                              ld_res, nullptr, nullptr, 0, stream_);
+    }
+    const int nct = (a.M + 31) / 32;
+    switch (nct) {
+        case 1: return launch<1>(a, stream);
+        case 2: return launch<2>(a, stream);
+        case 3: return launch<3>(a, stream);
+        case 4: return launch<4>(a, stream);
+        case 5: return launch<5>(a, stream);
+        case 6: return launch<6>(a, stream);
+        case 7: return launch<7>(a, stream);
+        case 8: return launch<8>(a, stream);
+        case 9: return launch<9>(a, stream);
+        case 10: return launch<10>(a, stream);
+        default: return MAGIC_ERR_UNSUPPORTED;  // M > 320: caller falls back to a library GEMM
+    }
+}
+
+}  // extern "C"

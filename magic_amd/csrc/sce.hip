@@ -1,0 +1,159 @@
+// Scaled-cosine-error loss over the masked rows, forward and backward fused
+// (model/autoencoder.py:242-245, model/loss_func.py:28-31).  One thread per masked row
+// (rows are n_dim <= 64 floats), fixed-order two-stage reductions for the loss and for the
+// gradient of a shared single-row target.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr float kEps = 1e-12f;  // F.normalize default eps
+constexpr int kMaxDim = 64;
+
+struct SceArgs {
+    int64_t n_mask;
+    int n_dim;
+    const int64_t *mask;
+    const float *x;
+    int64_t ld_x;
+    const float *t;
+    int64_t ld_t;
+    float alpha, grad_scale;
+    float *d_x;
+    float *ws_loss;  // [grid]
+    float *ws_dt;    // [grid, n_dim]
+    int grid;
+    float *loss;
+    float *d_trow;
+};
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_sce(SceArgs a) {
+    __shared__ float red[4];
+    float lsum = 0.f;
+    float dts[kMaxDim];  // only the first n_dim entries are live when d_trow is requested
+    const bool want_dt = a.d_trow != nullptr;
+    if (want_dt)
+        for (int j = 0; j < a.n_dim; ++j) dts[j] = 0.f;
+    const float inv_m = 1.f / (float)a.n_mask;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_mask; i += (int64_t)a.grid * 256) {
+        const int64_t row = a.mask[i];
+        const float *xr = a.x + row * a.ld_x;
+        const float *tr = a.ld_t > 0 ? a.t + row * a.ld_t : a.t;
+        float xx = 0.f, tt = 0.f, xt = 0.f;
+        for (int j = 0; j < a.n_dim; ++j) {
+            float xv = xr[j], tv = tr[j];
+            xx = fmaf(xv, xv, xx);
+            tt = fmaf(tv, tv, tt);
+            xt = fmaf(xv, tv, xt);
+        }
+        const float nx = sqrtf(xx), nt = sqrtf(tt);
+        const float dx = fmaxf(nx, kEps), dt = fmaxf(nt, kEps);
+        const float c = xt / (dx * dt);
+        const float base = 1.f - c;
+        float li, dldc;  // L_i = base^alpha ; dL_i/dc = -alpha base^(alpha-1)
+        if (a.alpha == 1.f) {
+            li = base;
+            dldc = -1.f;
+        } else if (a.alpha == 2.f) {
+            li = base * base;
+            dldc = -2.f * base;
+        } else if (a.alpha == 3.f) {
+            li = base * base * base;
+            dldc = -3.f * base * base;
+        } else {
+            li = powf(base, a.alpha);
+            dldc = -a.alpha * powf(base, a.alpha - 1.f);
+        }
+        lsum += li;
+        const float gc = dldc * inv_m * a.grad_scale;
+        // d c / d x = (t^ - (x^.t^) x^) / |x|   if |x| >= eps (clamp passes), else t^ / eps
+        float *dxr = a.d_x + row * a.ld_x;
+        const bool xpass = nx >= kEps, tpass = nt >= kEps;
+        for (int j = 0; j < a.n_dim; ++j) {
+            float xh = xr[j] / dx, th = tr[j] / dt;
+            float gx = xpass ? (th - c * xh) / dx : th / dx;
+            dxr[j] = gc * gx;
+            if (want_dt) {
+                float gt = tpass ? (xh - c * th) / dt : xh / dt;
+                dts[j] += gc * gt;
+            }
+        }
+    }
+    float bl = block_sum(lsum, red);
+    if (threadIdx.x == 0) a.ws_loss[blockIdx.x] = bl;
+    if (want_dt) {
+        for (int j = 0; j < a.n_dim; ++j) {
+            float v = block_sum(dts[j], red);
+            if (threadIdx.x == 0) a.ws_dt[(int64_t)blockIdx.x * a.n_dim + j] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sce_final(SceArgs a) {
+    __shared__ float red[4];
+    float t = 0.f;
+    for (int k = threadIdx.x; k < a.grid; k += 256) t += a.ws_loss[k];
+    t = block_sum(t, red);
+    if (threadIdx.x == 0) a.loss[0] = t / (float)a.n_mask;
+    if (a.d_trow) {
+        for (int j = 0; j < a.n_dim; ++j) {
+            float s = 0.f;
+            for (int k = threadIdx.x; k < a.grid; k += 256) s += a.ws_dt[(int64_t)k * a.n_dim + j];
+            s = block_sum(s, red);
+            if (threadIdx.x == 0) a.d_trow[j] = s;
+        }
+    }
+}
+
+int sce_grid(int64_t n_mask) { return magic::stride_grid(n_mask, 256, 1024); }
+
+}  // namespace
+
+extern "C" {
+
+size_t magic_sce_workspace_bytes(int64_t n_mask, int32_t n_dim) {
+    size_t g = sce_grid(n_mask > 0 ? n_mask : 1);
+    return magic::align_up(g * sizeof(float)) + magic::align_up(g * (size_t)(n_dim > 0 ? n_dim : 1) * sizeof(float)) + 256;
+}
+
+int magic_sce_fwd_bwd(int64_t n_rows, int32_t n_dim, int64_t n_mask, const int64_t *mask_idx, const float *x,
+                      int64_t ld_x, const float *target, int64_t ld_t, float alpha, float grad_scale, float *loss,
+                      float *d_x, float *d_target_row, void *workspace, size_t workspace_bytes, void *stream_) {
+    if (n_rows < 0 || n_mask <= 0 || n_dim <= 0 || n_dim > kMaxDim) return n_dim > kMaxDim ? MAGIC_ERR_UNSUPPORTED : MAGIC_ERR_INVALID_ARG;
+    if (!mask_idx || !x || !target || !loss || !d_x || ld_x < n_dim || (ld_t != 0 && ld_t < n_dim)) return MAGIC_ERR_INVALID_ARG;
+    if (d_target_row && ld_t != 0) return MAGIC_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    SceArgs a;
+    a.n_mask = n_mask;
+    a.n_dim = n_dim;
+    a.mask = mask_idx;
+    a.x = x;
+    a.ld_x = ld_x;
+    a.t = target;
+    a.ld_t = ld_t;
+    a.alpha = alpha;
+    a.grad_scale = grad_scale;
+    a.d_x = d_x;
+    a.grid = sce_grid(n_mask);
+    a.loss = loss;
+    a.d_trow = d_target_row;
+    magic::Arena ar(workspace, workspace_bytes);
+    a.ws_loss = ar.take<float>(a.grid);
+    a.ws_dt = ar.take<float>((size_t)a.grid * n_dim);
+    if (!ar.ok() || !a.ws_loss || !a.ws_dt) return MAGIC_ERR_WORKSPACE;
+    if (hipMemsetAsync(d_x, 0, sizeof(float) * (size_t)n_rows * ld_x, stream) != hipSuccess) return MAGIC_ERR_RUNTIME;
+    MAGIC_LAUNCH("sce_fwd_bwd", k_sce, a.grid, 256, 0, stream, a);
+    MAGIC_LAUNCH("sce_final", k_sce_final, 1, 256, 0, stream, a);
+    return magic::launch_status();
+}
+
+}  // extern "C"

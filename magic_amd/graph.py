@@ -1,0 +1,323 @@
+"""Minimal graph container exposing the DGLGraph subset MAGIC's hot path touches.
+
+The reference keeps graphs as ``dgl.DGLGraph`` objects (``model/gat.py:264-314``,
+``model/autoencoder.py:198-254``, ``model/train.py:39``, ``utils/loaddata.py:257-260``).
+DGL does not exist on the MI355X box, so this module provides exactly the calls
+those files make: ``ndata`` / ``edata`` dictionaries, ``num_nodes``,
+``number_of_edges``, ``edges``, ``clone``, ``to``, ``device``, ``local_scope``,
+``is_block`` and a module level :func:`batch`.
+
+Two behaviours of DGL 1.0 are kept on purpose because the reference depends on
+them:
+
+* ``clone()`` copies the feature *dictionaries* but shares the column tensors,
+  so an in-place write through the clone is visible in the original graph
+  (``model/autoencoder.py:198-210`` writes the mask token that way and then
+  reads ``g.ndata['attr'][mask_nodes]`` from the original at ``:242``).
+* ``batch()`` concatenates node ids with offsets; the destination-sorted
+  (CSC) and source-sorted (CSR) index arrays of the union graph are the
+  offset-shifted concatenation of the per-graph arrays, so they are reused
+  instead of re-sorted.
+
+The sparse structure (COO + stable CSC/CSR + the degree-binned work plan used
+by the HIP kernels) lives in a :class:`Structure` that clones share.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+# Segments up to LIGHT_MAX edges are reduced by one lane group in the fused
+# kernels; longer ones are cut into chunks of CHUNK edges that separate waves
+# reduce, with a fixed-order combine (bitwise reproducible, no atomics).
+LIGHT_MAX = 64
+CHUNK = 256
+
+
+class SegmentPlan:
+    """Work plan for one direction (CSC = by destination, CSR = by source).
+
+    ``ptr``        int32 [N+1]   segment offsets
+    ``heavy_node`` int32 [nh]    ids of nodes whose segment is longer than LIGHT_MAX
+    ``heavy_cptr`` int32 [nh+1]  first chunk of each heavy node
+    ``chunk_node`` int32 [nc]    heavy-node slot (index into heavy_node) of each chunk
+    ``chunk_beg`` / ``chunk_end`` int32 [nc]  edge range of each chunk
+    """
+
+    __slots__ = ("ptr", "heavy_node", "heavy_cptr", "chunk_node", "chunk_beg", "chunk_end",
+                 "n_heavy", "n_chunks")
+
+    def __init__(self, ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end):
+        self.ptr = ptr
+        self.heavy_node = heavy_node
+        self.heavy_cptr = heavy_cptr
+        self.chunk_node = chunk_node
+        self.chunk_beg = chunk_beg
+        self.chunk_end = chunk_end
+        self.n_heavy = int(heavy_node.numel())
+        self.n_chunks = int(chunk_node.numel())
+
+    def to(self, device):
+        return SegmentPlan(*(t.to(device) for t in (self.ptr, self.heavy_node, self.heavy_cptr,
+                                                     self.chunk_node, self.chunk_beg, self.chunk_end)))
+
+
+def build_segment_plan(ptr: torch.Tensor, light_max: int = LIGHT_MAX, chunk: int = CHUNK) -> SegmentPlan:
+    """Cut every segment longer than ``light_max`` into chunks of ``chunk`` edges.
+
+    Pure index arithmetic on ``ptr`` (any device); the result is a function of
+    ``ptr`` only, so it is identical on every rank and every run.
+    """
+    ptr64 = ptr.to(torch.int64)
+    deg = ptr64[1:] - ptr64[:-1]
+    heavy_node = torch.nonzero(deg > light_max, as_tuple=False).view(-1)
+    hdeg = deg[heavy_node]
+    nchunk = (hdeg + (chunk - 1)) // chunk
+    heavy_cptr = torch.zeros(heavy_node.numel() + 1, dtype=torch.int64, device=ptr.device)
+    if heavy_node.numel():
+        heavy_cptr[1:] = torch.cumsum(nchunk, 0)
+    nc = int(heavy_cptr[-1].item()) if heavy_node.numel() else 0
+    slot = torch.repeat_interleave(torch.arange(heavy_node.numel(), device=ptr.device), nchunk)
+    within = torch.arange(nc, device=ptr.device) - heavy_cptr[:-1][slot] if nc else slot
+    beg = ptr64[heavy_node][slot] + within * chunk if nc else slot
+    end = torch.minimum(beg + chunk, ptr64[heavy_node + 1][slot]) if nc else slot
+    i32 = torch.int32
+    return SegmentPlan(ptr.to(i32).contiguous(), heavy_node.to(i32), heavy_cptr.to(i32),
+                       slot.to(i32), beg.to(i32), end.to(i32))
+
+
+class Structure:
+    """COO edge list plus lazily built, cached CSC/CSR arrays (shared by clones)."""
+
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int):
+        assert src.dim() == 1 and src.shape == dst.shape
+        self.src = src.to(torch.int64)
+        self.dst = dst.to(torch.int64)
+        self.num_nodes = int(num_nodes)
+        self.num_edges = int(src.numel())
+        # CSC: edges sorted by destination (ties keep ascending edge id)
+        self.in_ptr = self.in_src = self.in_eid = None
+        # CSR: edges sorted by source; out_pos = position of that edge in CSC order
+        self.out_ptr = self.out_dst = self.out_eid = self.out_pos = None
+        self.plan_in: Optional[SegmentPlan] = None
+        self.plan_out: Optional[SegmentPlan] = None
+
+    @property
+    def device(self):
+        return self.src.device
+
+    def has_csr(self) -> bool:
+        return self.in_ptr is not None
+
+    def set_csr(self, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid):
+        self.in_ptr, self.in_src, self.in_eid = in_ptr, in_src, in_eid
+        self.out_ptr, self.out_dst, self.out_eid = out_ptr, out_dst, out_eid
+        # position of every original edge in CSC order, then looked up per CSR slot
+        inv = torch.empty(self.num_edges, dtype=torch.int32, device=in_eid.device)
+        inv[in_eid.long()] = torch.arange(self.num_edges, dtype=torch.int32, device=in_eid.device)
+        self.out_pos = inv[out_eid.long()].contiguous()
+        self.plan_in = build_segment_plan(in_ptr)
+        self.plan_out = build_segment_plan(out_ptr)
+
+    def ensure_csr(self):
+        """Build CSC/CSR with the HIP counting sort (device graphs only)."""
+        if self.has_csr():
+            return self
+        if self.src.device.type != "cuda":
+            raise RuntimeError("magic_amd: CSC/CSR construction runs on the MI355X only; "
+                               "move the graph with .to('cuda') first")
+        from . import _lib
+        self.set_csr(*_lib.csr_build(self.src, self.dst, self.num_nodes))
+        return self
+
+    def to(self, device) -> "Structure":
+        device = torch.device(device)
+        if device == self.src.device:
+            return self
+        s = Structure(self.src.to(device), self.dst.to(device), self.num_nodes)
+        if self.has_csr():
+            s.in_ptr, s.in_src, s.in_eid = (t.to(device) for t in (self.in_ptr, self.in_src, self.in_eid))
+            s.out_ptr, s.out_dst, s.out_eid = (t.to(device) for t in (self.out_ptr, self.out_dst, self.out_eid))
+            s.out_pos = self.out_pos.to(device)
+            s.plan_in, s.plan_out = self.plan_in.to(device), self.plan_out.to(device)
+        return s
+
+
+class Graph:
+    """Drop-in for the parts of ``dgl.DGLGraph`` the MAGIC hot path uses."""
+
+    is_block = False
+
+    def __init__(self, src, dst=None, num_nodes: Optional[int] = None, *, _structure: Structure = None):
+        if _structure is not None:
+            self._s = _structure
+        else:
+            if dst is None:  # dgl.graph((src, dst)) calling convention
+                src, dst = src
+            src = torch.as_tensor(src)
+            dst = torch.as_tensor(dst)
+            if num_nodes is None:
+                num_nodes = int(max(src.max().item(), dst.max().item())) + 1 if src.numel() else 0
+            self._s = Structure(src, dst, num_nodes)
+        self.ndata: Dict[str, torch.Tensor] = {}
+        self.edata: Dict[str, torch.Tensor] = {}
+        self._batch_num_nodes: Optional[List[int]] = None
+        self._batch_num_edges: Optional[List[int]] = None
+        self._cache: Dict[str, tuple] = {}
+
+    # DGL aliases: srcdata/dstdata are ndata on a homogeneous graph
+    @property
+    def srcdata(self):
+        return self.ndata
+
+    @property
+    def dstdata(self):
+        return self.ndata
+
+    @property
+    def structure(self) -> Structure:
+        return self._s
+
+    @property
+    def device(self):
+        return self._s.device
+
+    def num_nodes(self) -> int:
+        return self._s.num_nodes
+
+    number_of_nodes = num_nodes
+
+    def num_edges(self) -> int:
+        return self._s.num_edges
+
+    number_of_edges = num_edges
+
+    def number_of_dst_nodes(self) -> int:
+        return self._s.num_nodes
+
+    def edges(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self._s.src, self._s.dst
+
+    def in_degrees(self) -> torch.Tensor:
+        return torch.bincount(self._s.dst, minlength=self._s.num_nodes)
+
+    def batch_num_nodes(self):
+        return list(self._batch_num_nodes) if self._batch_num_nodes is not None else [self.num_nodes()]
+
+    def batch_num_edges(self):
+        return list(self._batch_num_edges) if self._batch_num_edges is not None else [self.num_edges()]
+
+    def clone(self) -> "Graph":
+        """Structure and feature *dictionaries* are copied, column tensors are shared
+        (DGL 1.0 ``Frame.clone`` semantics the reference relies on)."""
+        g = Graph(None, _structure=self._s)
+        g.ndata = dict(self.ndata)
+        g.edata = dict(self.edata)
+        g._batch_num_nodes = None if self._batch_num_nodes is None else list(self._batch_num_nodes)
+        g._batch_num_edges = None if self._batch_num_edges is None else list(self._batch_num_edges)
+        g._cache = self._cache  # keyed by tensor identity, safe to share
+        return g
+
+    def to(self, device) -> "Graph":
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if device == self.device:
+            return self
+        g = Graph(None, _structure=self._s.to(device))
+        g.ndata = {k: v.to(device) for k, v in self.ndata.items()}
+        g.edata = {k: v.to(device) for k, v in self.edata.items()}
+        g._batch_num_nodes, g._batch_num_edges = self._batch_num_nodes, self._batch_num_edges
+        return g
+
+    @contextlib.contextmanager
+    def local_scope(self):
+        """Feature keys added or rebound inside the scope are dropped afterwards;
+        in-place writes to existing tensors persist (as in DGL)."""
+        nd, ed = dict(self.ndata), dict(self.edata)
+        try:
+            yield
+        finally:
+            self.ndata, self.edata = nd, ed
+
+    # ---- helpers used by the HIP operators -------------------------------------------
+    def edge_types_csc(self) -> Optional[torch.Tensor]:
+        """Edge type ids (int32) in CSC order when ``edata['attr']`` is the one-hot of an
+        integer type (``utils/loaddata.py:259``); ``None`` for dense edge attributes."""
+        attr = self.edata.get("attr")
+        if attr is None:
+            return None
+        key = ("etype", attr.data_ptr(), attr._version, tuple(attr.shape))
+        hit = self._cache.get("etype")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        types = None
+        if attr.dim() == 2 and attr.numel() > 0:
+            t = self.edata.get("type")
+            if t is not None and t.numel() == attr.shape[0]:
+                t = t.view(-1).long()
+                ok = bool(((t >= 0) & (t < attr.shape[1])).all()) and \
+                    bool((attr.gather(1, t.clamp(0, attr.shape[1] - 1).view(-1, 1)).view(-1) == 1).all()) and \
+                    bool((attr.sum(1) == 1).all()) and bool((attr.abs().sum(1) == 1).all())
+                if ok:
+                    types = t
+            else:
+                mx, am = attr.max(1)
+                if bool((mx == 1).all()) and bool((attr.abs().sum(1) == 1).all()):
+                    types = am
+        res = None
+        if types is not None:
+            s = self._s.ensure_csr()
+            res = types.to(torch.int32)[s.in_eid.long()].contiguous()
+        self._cache["etype"] = (key, res)
+        return res
+
+
+def graph(data, num_nodes: Optional[int] = None) -> Graph:
+    """``dgl.graph((src, dst), num_nodes=N)`` equivalent."""
+    src, dst = data
+    return Graph(src, dst, num_nodes)
+
+
+def batch(graphs: Sequence[Graph]) -> Graph:
+    """Union graph with node-id offsets (``dgl.batch``, used at ``model/train.py:39``).
+
+    When every component already carries its CSC/CSR arrays the union's arrays are
+    their offset-shifted concatenation: destinations of component i are all smaller
+    than those of component i+1 and edge ids keep their relative order, so this equals
+    a stable sort of the union edge list bit for bit.
+    """
+    graphs = list(graphs)
+    assert len(graphs) > 0
+    dev = graphs[0].device
+    n_off, e_off = [0], [0]
+    for g in graphs:
+        n_off.append(n_off[-1] + g.num_nodes())
+        e_off.append(e_off[-1] + g.num_edges())
+    src = torch.cat([g._s.src + n_off[i] for i, g in enumerate(graphs)])
+    dst = torch.cat([g._s.dst + n_off[i] for i, g in enumerate(graphs)])
+    s = Structure(src, dst, n_off[-1])
+    if all(g._s.has_csr() for g in graphs):
+        def cat_ptr(attr):
+            parts = [getattr(graphs[0]._s, attr)]
+            for i, g in enumerate(graphs[1:], 1):
+                parts.append(getattr(g._s, attr)[1:] + e_off[i])
+            return torch.cat(parts).to(torch.int32)
+
+        def cat_off(attr, offs):
+            return torch.cat([getattr(g._s, attr) + offs[i] for i, g in enumerate(graphs)]).to(torch.int32)
+        s.set_csr(cat_ptr("in_ptr"), cat_off("in_src", n_off), cat_off("in_eid", e_off),
+                  cat_ptr("out_ptr"), cat_off("out_dst", n_off), cat_off("out_eid", e_off))
+    out = Graph(None, _structure=s)
+    for k in graphs[0].ndata:
+        if all(k in g.ndata for g in graphs):
+            out.ndata[k] = torch.cat([g.ndata[k] for g in graphs], 0)
+    for k in graphs[0].edata:
+        if all(k in g.edata for g in graphs):
+            out.edata[k] = torch.cat([g.edata[k] for g in graphs], 0)
+    out._batch_num_nodes = [g.num_nodes() for g in graphs]
+    out._batch_num_edges = [g.num_edges() for g in graphs]
+    assert dev == out.device
+    return out

@@ -1,0 +1,286 @@
+"""GAT / GATConv with the reference's Python API, running on hand-written HIP kernels.
+
+Mirrors ``model/gat.py`` of the reference: same class names, constructor arguments,
+parameter names, construction order (so seeds and state dicts carry over) and
+``forward`` signatures.  The arithmetic of ``GATConv.forward`` (``model/gat.py:264-340``)
+is re-expressed for the MI355X:
+
+* node phase -- ``fc`` (``:284``), the per-head scores ``eh``/``et`` (``:291-292``) and the
+  residual projection ``res_fc`` (``:323``) are one fp32 MFMA GEMM against an augmented
+  weight ``W_aug = [W_fc ; fold(W_fc, attn_h) ; fold(W_fc, attn_t) ; W_res]`` where
+  ``fold(W, a)[h, :] = sum_d a[h, d] * W[h*D + d, :]`` (``eh = (h W^T) . attn_h`` is linear
+  in ``h``, so it is a GEMM column).  The fold is a handful of tiny differentiable torch
+  ops; autograd therefore delivers the gradients of ``fc.weight``, ``attn_h``, ``attn_t``
+  and ``res_fc.weight`` from the single ``d W_aug``.
+* edge phase -- ``edge_fc`` + ``attn_e`` (``:297-299``) collapse the same way into a
+  ``[e_dim, H]`` table indexed by edge type when ``edata['attr']`` is one-hot (it always is
+  in MAGIC: ``utils/loaddata.py:259``), so the reference's ``[E, H*D]`` temporary never
+  exists; ``:302-335`` (logits, leaky ReLU, edge softmax, aggregation, bias, residual,
+  PReLU) are the fused HIP kernels of ``csrc/gat_fwd.hip`` / ``csrc/gat_bwd.hip``.
+
+There is no CPU implementation here: tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..graph import Graph
+from ..utils.utils import create_activation
+
+
+def expand_as_pair(in_dim):
+    """``dgl.utils.expand_as_pair`` for feature sizes (``model/gat.py:177``)."""
+    if isinstance(in_dim, tuple):
+        return in_dim
+    return in_dim, in_dim
+
+
+def _pad_head_dim(d: int) -> int:
+    """Head widths the kernels are compiled for: 4 floats per lane, power-of-two lanes."""
+    for p in (4, 8, 16, 32, 64):
+        if d <= p:
+            return p
+    raise _lib.MagicHipError(f"head width {d} > 64 has no compiled kernel")
+
+
+def _fold(w: torch.Tensor, attn: torch.Tensor, H: int, D: int) -> torch.Tensor:
+    """[H*D, F] weight and [1,H,D] attention vector -> [H, F] score weight."""
+    return (w.view(H, D, -1) * attn.view(H, D, 1)).sum(1)
+
+
+class _GATLayerFn(torch.autograd.Function):
+    """proj GEMM + fused edge phase; backward = HIP edge-phase backward + two GEMMs."""
+
+    @staticmethod
+    def forward(ctx, h, w_aug, edge_term, bias, prelu_w, struct, cfg):
+        H, Dp, C = cfg["H"], cfg["Dp"], cfg["C"]
+        res_c = cfg["res_c"]
+        h = h.contiguous() if h.stride(-1) != 1 else h
+        hs, score, res = _lib.proj_fwd(h, w_aug, C, 2 * H, res_c)
+        if cfg["res_identity"]:
+            res = h
+        etype = cfg["etype_csc"]
+        if etype is not None:
+            table, ee_csc = edge_term.contiguous(), None
+        else:
+            table, ee_csc = None, edge_term[struct.in_eid.long()].contiguous()
+        want_pre = prelu_w is not None and cfg["need_grad"]
+        out, pre, attn = _lib.gat_fwd(struct, H, Dp, hs, score[:, :H], score[:, H:], table, etype, ee_csc,
+                                      cfg["slope"], bias, res, prelu_w, want_pre)
+        ctx.struct, ctx.cfg = struct, cfg
+        ctx.save_for_backward(h, w_aug, hs, attn, pre, prelu_w)
+        ctx.mark_non_differentiable(attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, d_out, _d_attn):
+        h, w_aug, hs, attn, pre, prelu_w = ctx.saved_tensors
+        struct, cfg = ctx.struct, ctx.cfg
+        H, Dp, C, res_c = cfg["H"], cfg["Dp"], cfg["C"], cfg["res_c"]
+        N = h.shape[0]
+        Ctot = w_aug.shape[0]
+        d_y = torch.empty(N, Ctot, dtype=torch.float32, device=h.device)
+        if res_c and (C + 2 * H) % 4 == 0:
+            d_pre = d_y[:, C + 2 * H:]
+        else:
+            d_pre = torch.empty(N, C, dtype=torch.float32, device=h.device)
+        etype = cfg["etype_csc"]
+        d_table, rec, d_bias, d_prelu = _lib.gat_bwd(
+            struct, H, Dp, hs, attn, etype, cfg["e_dim"], cfg["slope"], pre, prelu_w, d_out, d_pre, d_y,
+            cfg["has_bias"])
+        if res_c and d_pre.data_ptr() != d_y[:, C + 2 * H:].data_ptr():
+            d_y[:, C + 2 * H:] = d_pre
+        d_h = d_w = d_edge = None
+        if ctx.needs_input_grad[0]:
+            d_h = d_y @ w_aug
+            if cfg["res_identity"]:
+                d_h = d_h + d_pre
+        if ctx.needs_input_grad[1]:
+            d_w = d_y.t() @ h
+        if ctx.needs_input_grad[2]:
+            if etype is not None:
+                d_edge = d_table
+            else:
+                d_edge = torch.empty(struct.num_edges, H, dtype=torch.float32, device=h.device)
+                d_edge[struct.in_eid.long()] = rec[:, H:]
+        return d_h, d_w, d_edge, d_bias, d_prelu, None, None
+
+
+class GATConv(nn.Module):
+    """Edge-feature-aware graph attention layer (``model/gat.py:136-340``)."""
+
+    def __init__(self, in_dim, e_dim, out_dim, n_heads, feat_drop=0.0, attn_drop=0.0, negative_slope=0.2,
+                 residual=False, activation=None, allow_zero_in_degree=False, bias=True, norm=None,
+                 concat_out=True):
+        super().__init__()
+        self.n_heads = n_heads
+        self.src_feat, self.dst_feat = expand_as_pair(in_dim)
+        self.edge_feat = e_dim
+        self.out_feat = out_dim
+        self.allow_zero_in_degree = allow_zero_in_degree
+        self.concat_out = concat_out
+        if isinstance(in_dim, tuple):
+            raise NotImplementedError("bipartite (src, dst) inputs are not used by MAGIC and have no HIP kernel")
+        # same construction order as model/gat.py:189-210 (RNG stream and state-dict keys)
+        self.fc_node_embedding = nn.Linear(self.src_feat, out_dim * n_heads, bias=False)
+        self.fc = nn.Linear(self.src_feat, out_dim * n_heads, bias=False)
+        self.edge_fc = nn.Linear(e_dim, out_dim * n_heads, bias=False)
+        self.attn_h = nn.Parameter(torch.FloatTensor(size=(1, n_heads, out_dim)))
+        self.attn_e = nn.Parameter(torch.FloatTensor(size=(1, n_heads, out_dim)))
+        self.attn_t = nn.Parameter(torch.FloatTensor(size=(1, n_heads, out_dim)))
+        self.feat_drop = nn.Dropout(feat_drop)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.leaky_relu = nn.LeakyReLU(negative_slope)
+        if bias:
+            self.bias = nn.Parameter(torch.FloatTensor(size=(1, n_heads, out_dim)))
+        else:
+            self.register_buffer("bias", None)
+        if residual:
+            if self.dst_feat != n_heads * out_dim:
+                self.res_fc = nn.Linear(self.dst_feat, n_heads * out_dim, bias=False)
+            else:
+                self.res_fc = nn.Identity()
+        else:
+            self.register_buffer("res_fc", None)
+        self.reset_parameters()
+        self.activation = activation
+        self.norm = norm
+        if norm is not None:
+            self.norm = norm(n_heads * out_dim)
+
+    def reset_parameters(self):
+        """``model/gat.py:227-240``."""
+        gain = nn.init.calculate_gain("relu")
+        nn.init.xavier_normal_(self.edge_fc.weight, gain=gain)
+        nn.init.xavier_normal_(self.fc.weight, gain=gain)
+        nn.init.xavier_normal_(self.attn_h, gain=gain)
+        nn.init.xavier_normal_(self.attn_e, gain=gain)
+        nn.init.xavier_normal_(self.attn_t, gain=gain)
+        if self.bias is not None:
+            nn.init.constant_(self.bias, 0)
+        if isinstance(self.res_fc, nn.Linear):
+            nn.init.xavier_normal_(self.res_fc.weight, gain=gain)
+
+    def set_allow_zero_in_degree(self, set_value):
+        self.allow_zero_in_degree = set_value
+
+    # ---------------------------------------------------------------------------------
+    def _augmented_weight(self, Dp: int) -> torch.Tensor:
+        H, D = self.n_heads, self.out_feat
+        w = self.fc.weight
+        parts = []
+        if Dp != D:
+            wp = torch.zeros(H, Dp, w.shape[1], dtype=w.dtype, device=w.device)
+            wp[:, :D] = w.view(H, D, -1)
+            parts.append(wp.view(H * Dp, -1))
+        else:
+            parts.append(w)
+        parts.append(_fold(w, self.attn_h, H, D))
+        parts.append(_fold(w, self.attn_t, H, D))
+        if isinstance(self.res_fc, nn.Linear):
+            rw = self.res_fc.weight
+            if Dp != D:
+                rp = torch.zeros(H, Dp, rw.shape[1], dtype=rw.dtype, device=rw.device)
+                rp[:, :D] = rw.view(H, D, -1)
+                rw = rp.view(H * Dp, -1)
+            parts.append(rw)
+        return torch.cat(parts, 0)
+
+    def forward(self, graph: Graph, feat, get_attention=False):
+        if isinstance(feat, tuple):
+            raise NotImplementedError("bipartite (src, dst) inputs are not used by MAGIC and have no HIP kernel")
+        if feat.device.type != "cuda":
+            raise _lib.MagicHipError("magic_amd.GATConv runs on the MI355X only (no CPU fallback); "
+                                     "move the graph and the model to 'cuda'")
+        if self.attn_drop.p != 0.0 and self.training:
+            raise NotImplementedError("attn_drop > 0 is never used by MAGIC (model/autoencoder.py:143,162)")
+        H, D = self.n_heads, self.out_feat
+        Dp = _pad_head_dim(D)
+        C = H * Dp
+        struct = graph.structure.ensure_csr()
+        h = self.feat_drop(feat)                                       # gat.py:283
+        res_identity = isinstance(self.res_fc, nn.Identity)
+        if res_identity and Dp != D:
+            raise _lib.MagicHipError("identity residual with a padded head width is not supported")
+        w_aug = self._augmented_weight(Dp)
+        # edge score term: [e_dim, H] table (one-hot attributes) or dense [E, H]
+        table = _fold(self.edge_fc.weight, self.attn_e, H, D).t()      # gat.py:297-299 collapsed
+        etype_csc = graph.edge_types_csc()
+        if etype_csc is not None:
+            edge_term = table.contiguous()
+        else:
+            edge_term = graph.edata["attr"].to(torch.float32) @ table
+        fuse_act = isinstance(self.activation, nn.PReLU) and self.activation.weight.numel() == 1 \
+            and self.norm is None and self.concat_out
+        prelu_w = self.activation.weight if fuse_act else None
+        bias = None
+        if self.bias is not None:
+            bias = self.bias.view(H, D)
+            if Dp != D:
+                bias = torch.cat([bias, bias.new_zeros(H, Dp - D)], 1)
+            bias = bias.reshape(-1)
+        need_grad = torch.is_grad_enabled()
+        cfg = dict(H=H, Dp=Dp, C=C, res_c=C if isinstance(self.res_fc, nn.Linear) else 0,
+                   res_identity=res_identity, etype_csc=etype_csc, e_dim=self.edge_feat,
+                   slope=self.leaky_relu.negative_slope, has_bias=bias is not None, need_grad=need_grad)
+        out, attn = _GATLayerFn.apply(h, w_aug, edge_term, bias, prelu_w, struct, cfg)
+        rst = out
+        if Dp != D:
+            rst = out.view(-1, H, Dp)[:, :, :D].reshape(-1, H * D)
+        if not self.concat_out:                                        # gat.py:328-329
+            rst = rst.reshape(-1, H, D).mean(dim=1)
+        if self.norm is not None:                                      # gat.py:331-332
+            rst = self.norm(rst)
+        if self.activation is not None and not fuse_act:               # gat.py:334-335
+            rst = self.activation(rst)
+        if get_attention:
+            a = torch.empty_like(attn)
+            a[struct.in_eid.long()] = attn.abs()
+            return rst, a.unsqueeze(-1)
+        return rst
+
+
+class GAT(nn.Module):
+    """Multi-layer GAT (``model/gat.py:23-133``)."""
+
+    def __init__(self, n_dim, e_dim, hidden_dim, out_dim, n_layers, n_heads, n_heads_out, activation,
+                 feat_drop, attn_drop, negative_slope, residual, norm, concat_out=False, encoding=False):
+        super().__init__()
+        self.out_dim = out_dim
+        self.n_heads = n_heads
+        self.n_layers = n_layers
+        self.gats = nn.ModuleList()
+        self.concat_out = concat_out
+        last_activation = create_activation(activation) if encoding else None
+        last_residual = (encoding and residual)
+        last_norm = norm if encoding else None
+        if self.n_layers == 1:
+            self.gats.append(GATConv(n_dim, e_dim, out_dim, n_heads_out, feat_drop, attn_drop, negative_slope,
+                                     last_residual, norm=last_norm, concat_out=self.concat_out))
+        else:
+            self.gats.append(GATConv(n_dim, e_dim, hidden_dim, n_heads, feat_drop, attn_drop, negative_slope,
+                                     residual, create_activation(activation), norm=norm,
+                                     concat_out=self.concat_out))
+            for _ in range(1, self.n_layers - 1):
+                self.gats.append(GATConv(hidden_dim * self.n_heads, e_dim, hidden_dim, n_heads, feat_drop,
+                                         attn_drop, negative_slope, residual, create_activation(activation),
+                                         norm=norm, concat_out=self.concat_out))
+            self.gats.append(GATConv(hidden_dim * self.n_heads, e_dim, out_dim, n_heads_out, feat_drop,
+                                     attn_drop, negative_slope, last_residual, last_activation, norm=last_norm,
+                                     concat_out=self.concat_out))
+        self.head = nn.Identity()
+
+    def forward(self, g, input_feature, return_hidden=False):
+        h = input_feature
+        hidden_list = []
+        for layer in range(self.n_layers):
+            h = self.gats[layer](g, h)
+            hidden_list.append(h)
+        if return_hidden:
+            return self.head(h), hidden_list
+        return self.head(h)
+
+    def reset_classifier(self, num_classes):
+        self.head = nn.Linear(self.n_heads * self.out_dim, num_classes)
