@@ -81,7 +81,8 @@ class _GATLayerFn(torch.autograd.Function):
         H, Dp, C, res_c = cfg["H"], cfg["Dp"], cfg["C"], cfg["res_c"]
         N = h.shape[0]
         Ctot = w_aug.shape[0]
-        d_y = torch.empty(N, Ctot, dtype=torch.float32, device=h.device)
+        ld = (Ctot + 3) // 4 * 4  # float4 row stores need 16-byte aligned rows
+        d_y = torch.empty(N, ld, dtype=torch.float32, device=h.device)[:, :Ctot]
         if res_c and (C + 2 * H) % 4 == 0:
             d_pre = d_y[:, C + 2 * H:]
         else:

@@ -1,0 +1,132 @@
+"""CSR build (bit-exact), KNN search (bit-exact indices on tie-free data) and the SCE kernel
+against their oracles, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import csr_oracle, knn_oracle
+from oracle import gat_oracle as O
+from tests.util import rel_err, small_graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,e,hub", [(1, 0, 0), (50, 0, 0), (300, 1500, 0), (5000, 40000, 3000), (70000, 300000, 0)])
+def test_csr_build_bit_exact(cuda, n, e, hub):
+    from magic_amd import _lib
+    from magic_amd.graph import Structure, LIGHT_MAX, CHUNK
+    if e:
+        src, dst, _, _ = small_graph(n, e, 4, 4, seed=n, hub_deg=hub, hub_out=hub // 2)
+    else:
+        src = dst = np.zeros(0, np.int64)
+    s = Structure(torch.from_numpy(src).to(cuda), torch.from_numpy(dst).to(cuda), n).ensure_csr()
+    want = csr_oracle.build(src, dst, n)
+    got = (s.in_ptr, s.in_src, s.in_eid, s.out_ptr, s.out_dst, s.out_eid)
+    for w, g_ in zip(want, got):
+        assert g_.dtype == torch.int32
+        assert np.array_equal(w, g_.cpu().numpy())
+    # edge position map and the chunk plan
+    inv = np.empty(src.size, np.int32)
+    inv[want[2]] = np.arange(src.size, dtype=np.int32)
+    assert np.array_equal(inv[want[5]], s.out_pos.cpu().numpy())
+    for ptr, plan in ((want[0], s.plan_in), (want[3], s.plan_out)):
+        hv, cp, cn, cb, ce = csr_oracle.segment_plan(ptr, LIGHT_MAX, CHUNK)
+        assert np.array_equal(hv, plan.heavy_node.cpu().numpy())
+        assert np.array_equal(cp, plan.heavy_cptr.cpu().numpy())
+        assert np.array_equal(cn, plan.chunk_node.cpu().numpy())
+        assert np.array_equal(cb, plan.chunk_beg.cpu().numpy())
+        assert np.array_equal(ce, plan.chunk_end.cpu().numpy())
+
+
+def test_batch_csr_equals_direct_sort(cuda):
+    from magic_amd.graph import Graph, batch, Structure
+    gs = []
+    for i in range(5):
+        src, dst, nt, et = small_graph(200 + 37 * i, 900 + 100 * i, 4, 4, seed=100 + i, hub_deg=90)
+        g = Graph(torch.from_numpy(src), torch.from_numpy(dst), 200 + 37 * i).to(cuda)
+        g.structure.ensure_csr()
+        gs.append(g)
+    bg = batch(gs)
+    direct = Structure(bg.edges()[0], bg.edges()[1], bg.num_nodes()).ensure_csr()
+    for name in ("in_ptr", "in_src", "in_eid", "out_ptr", "out_dst", "out_eid", "out_pos"):
+        assert torch.equal(getattr(bg.structure, name), getattr(direct, name)), name
+
+
+@pytest.mark.parametrize("nt,nq,d,k", [(5000, 777, 64, 10), (300, 130, 64, 10), (20000, 300, 64, 200),
+                                        (400, 200, 256, 8), (100, 50, 2048, 2), (3000, 257, 32, 5)])
+def test_knn_matches_exact_oracle(cuda, nt, nq, d, k):
+    from magic_amd import _lib
+    rng = np.random.default_rng(nt + d)
+    train = rng.standard_normal((nt, d)).astype(np.float32)
+    query = rng.standard_normal((nq, d)).astype(np.float32)
+    query[: min(20, nq)] = train[: min(20, nq)]   # exact hits: distance 0 must come first
+    dist, idx = _lib.knn_topk(torch.from_numpy(train).to(cuda), torch.from_numpy(query).to(cuda), k)
+    wd, wi = knn_oracle.exact_topk(train, query, k)
+    assert np.array_equal(idx.cpu().numpy(), wi)            # tie-free data: bit-exact indices
+    assert np.abs(dist.cpu().numpy() - wd).max() < 1e-6     # |q|^2-2qt+|t|^2 vs (q-t)^2 in f64
+
+
+def test_knn_ties_ordered_by_index_and_merge(cuda):
+    from magic_amd import _lib
+    rng = np.random.default_rng(1)
+    base = rng.standard_normal((50, 64)).astype(np.float32)
+    train = np.concatenate([base, base, base])               # every row three times
+    query = base[:17] + 0.01
+    dist, idx = _lib.knn_topk(torch.from_numpy(train).to(cuda), torch.from_numpy(query).to(cuda), 6)
+    wd, wi = knn_oracle.exact_topk(train, query, 6)
+    assert np.array_equal(idx.cpu().numpy(), wi)
+    # shards + merge == single search
+    parts_d, parts_i = [], []
+    for lo in (0, 60, 120):
+        hi = min(lo + 60, 150)
+        d_, i_ = _lib.knn_topk(torch.from_numpy(train[lo:hi]).to(cuda), torch.from_numpy(query).to(cuda), 6, lo)
+        parts_d.append(d_)
+        parts_i.append(i_)
+    md, mi = _lib.knn_merge(torch.stack(parts_d), torch.stack(parts_i))
+    assert torch.equal(mi, idx) and torch.equal(md, dist)
+
+
+@pytest.mark.parametrize("n_dim,alpha,single", [(5, 3, False), (11, 3, True), (8, 2, False), (8, 1.5, True)])
+def test_sce_kernel(cuda, n_dim, alpha, single):
+    from magic_amd.model.loss_func import sce_loss_masked
+    torch.manual_seed(0)
+    n = 1000
+    x = torch.randn(n, n_dim)
+    x[3] = 0.0                                    # zero row: F.normalize's eps clamp
+    tgt = torch.randn(1, n_dim) * 0.1 if single else torch.nn.functional.one_hot(
+        torch.randint(0, n_dim, (n,)), n_dim).float()
+    mask = torch.randperm(n)[: n // 2]
+    if not bool((mask == 3).any()):     # masks come from a permutation: no duplicates
+        mask[0] = 3
+    xo = x.double().requires_grad_(True)
+    to = tgt.double().requires_grad_(single)
+    lo = O.sce_loss(xo[mask], to.expand(mask.numel(), -1) if single else to[mask], alpha=alpha)
+    lo.backward()
+    xm = x.to(cuda).requires_grad_(True)
+    tm = tgt.to(cuda).requires_grad_(single)
+    lm = sce_loss_masked(xm, tm, mask.to(cuda), alpha)
+    (lm * 1.0).backward()
+    assert abs(float(lm) - float(lo)) < 1e-5 * max(1.0, abs(float(lo)))
+    assert rel_err(xm.grad, xo.grad) < 1e-4
+    if single:
+        assert rel_err(tm.grad, to.grad) < 1e-4
+
+
+def test_sce_zero_token_target(cuda):
+    """Zero-initialised mask token as target (model/autoencoder.py:170): cos = 0, loss = 1,
+    gradient through the eps clamp of F.normalize."""
+    from magic_amd.model.loss_func import sce_loss_masked
+    torch.manual_seed(1)
+    x = torch.randn(64, 5)
+    mask = torch.arange(0, 64, 2)
+    to = torch.zeros(1, 5, dtype=torch.float64, requires_grad=True)
+    xo = x.double().requires_grad_(True)
+    lo = O.sce_loss(xo[mask], to.expand(mask.numel(), -1), alpha=3)
+    lo.backward()
+    tm = torch.zeros(1, 5, device=cuda, requires_grad=True)
+    xm = x.to(cuda).requires_grad_(True)
+    lm = sce_loss_masked(xm, tm, mask.to(cuda), 3)
+    lm.backward()
+    assert float(lm) == pytest.approx(1.0, abs=1e-6)
+    assert rel_err(tm.grad, to.grad) < 1e-4
+    assert rel_err(xm.grad, xo.grad) < 1e-4 or float(xo.grad.abs().max()) == 0.0

@@ -1,0 +1,161 @@
+"""HIP GAT layer / auto-encoder vs the torch-CPU oracle (fp32 and fp64 anchor).
+
+Tolerance: north star asks embeddings / loss within 1e-4 relative in fp32; layer outputs and
+gradients are compared against the fp64 oracle at 2e-4 of the tensor's max magnitude (the
+fp32 oracle itself sits at ~1e-6 from the fp64 one)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import rel_err, small_graph, to_graph, to_ograph
+from oracle import gat_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def _layer_pair(in_dim, e_dim, out_dim, heads, residual, act, seed, dev):
+    from magic_amd.model.gat import GATConv
+    torch.manual_seed(seed)
+    act_o = torch.nn.PReLU() if act else None
+    ref = O.GATConv(in_dim, e_dim, out_dim, heads, 0.0, 0.0, 0.2, residual, act_o, norm=None, concat_out=True)
+    with torch.no_grad():
+        if ref.bias is not None:
+            ref.bias.normal_(0, 0.1)
+        if act:
+            ref.activation.weight.fill_(0.3)
+    mine = GATConv(in_dim, e_dim, out_dim, heads, 0.0, 0.0, 0.2, residual, torch.nn.PReLU() if act else None,
+                   norm=None, concat_out=True)
+    mine.load_state_dict(ref.state_dict())
+    return ref.double(), mine.to(dev)
+
+
+@pytest.mark.parametrize("cfg", [
+    # in_dim, e_dim, out_dim(per head), heads, residual, prelu, n, e, hub_in, hub_out
+    (64, 17, 16, 4, True, True, 600, 2500, 300, 200),     # entity-level encoder layer (identity residual)
+    (5, 17, 16, 4, True, True, 500, 2000, 150, 0),        # layer 0: linear residual, tiny input width
+    (64, 17, 5, 1, False, False, 400, 1500, 100, 90),     # decoder: 1 head, width 5 (padded to 8)
+    (256, 20, 64, 4, True, True, 300, 1800, 280, 270),    # batch-level encoder layer
+    (64, 23, 11, 1, False, False, 300, 900, 0, 0),        # decoder width 11 (padded to 16)
+    (8, 4, 64, 4, True, True, 64, 0, 0, 0),               # no edges at all
+])
+def test_gatconv_forward_backward(cuda, cfg):
+    in_dim, e_dim, out_dim, heads, residual, act, n, e, hub_in, hub_out = cfg
+    if e == 0:
+        src = dst = np.zeros(0, np.int64)
+        rng = np.random.default_rng(0)
+        ntype, etype = rng.integers(0, 4, n), np.zeros(0, np.int64)
+    else:
+        src, dst, ntype, etype = small_graph(n, e, 4, e_dim, seed=7, hub_deg=hub_in, hub_out=hub_out)
+    og = to_ograph(src, dst, n, ntype, etype, 4, e_dim, torch.float64)
+    g = to_graph(src, dst, n, ntype, etype, 4, e_dim, cuda)
+    ref, mine = _layer_pair(in_dim, e_dim, out_dim, heads, residual, act, 3, cuda)
+    torch.manual_seed(11)
+    x = torch.randn(n, in_dim)
+    xo = x.double().requires_grad_(True)
+    xm = x.to(cuda).requires_grad_(True)
+    yo, ao = ref(og, xo, get_attention=True)
+    ym, am = mine(g, xm, get_attention=True)
+    assert ym.shape == yo.shape
+    assert rel_err(ym, yo) < TOL
+    if e:
+        assert rel_err(am, ao) < TOL
+    w = torch.randn_like(yo)
+    (yo * w).sum().backward()
+    (ym * w.float().to(cuda)).sum().backward()
+    assert rel_err(xm.grad, xo.grad) < TOL
+    for (k, po), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        if po.grad is None:
+            assert pm.grad is None or float(pm.grad.abs().max()) == 0.0, k
+            continue
+        assert pm.grad is not None, k
+        assert rel_err(pm.grad, po.grad) < TOL, k
+
+
+def test_dense_edge_attr_path(cuda):
+    """edata['attr'] that is not one-hot takes the dense per-edge score path."""
+    n, e_dim = 300, 6
+    src, dst, ntype, etype = small_graph(n, 1200, 4, e_dim, seed=5, hub_deg=120)
+    og = to_ograph(src, dst, n, ntype, etype, 4, e_dim, torch.float64)
+    g = to_graph(src, dst, n, ntype, etype, 4, e_dim, cuda)
+    torch.manual_seed(2)
+    dense = torch.rand(src.size, e_dim)
+    og.edata["attr"] = dense.double()
+    g.edata["attr"] = dense.to(cuda)
+    del g.edata["type"]
+    ref, mine = _layer_pair(64, e_dim, 16, 4, True, True, 4, cuda)
+    x = torch.randn(n, 64)
+    xo, xm = x.double().requires_grad_(True), x.to(cuda).requires_grad_(True)
+    yo, ym = ref(og, xo), mine(g, xm)
+    assert rel_err(ym, yo) < TOL
+    yo.sum().backward()
+    ym.sum().backward()
+    assert rel_err(xm.grad, xo.grad) < TOL
+    assert rel_err(mine.edge_fc.weight.grad, ref.edge_fc.weight.grad) < TOL
+    assert rel_err(mine.attn_e.grad, ref.attn_e.grad) < TOL
+
+
+def _model_pair(n_dim, e_dim, hidden, layers, dev, seed=0, alias=True):
+    from magic_amd.model.autoencoder import GMAEModel
+    torch.manual_seed(seed)
+    ref = O.build_model(n_dim, e_dim, hidden, layers, alias_clone=alias)
+    torch.manual_seed(seed)
+    mine = GMAEModel(n_dim, e_dim, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3,
+                     alias_clone=alias)
+    # identical construction order and RNG consumption => identical initial weights
+    for (k1, v1), (k2, v2) in zip(ref.state_dict().items(), mine.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    with torch.no_grad():  # a non-zero mask token so that both SCE branches are exercised
+        ref.enc_mask_token.normal_(0, 0.3)
+        mine.enc_mask_token.copy_(ref.enc_mask_token)
+    return ref, mine.to(dev)
+
+
+@pytest.mark.parametrize("shape,alias", [((5, 17, 64, 3), True), ((5, 17, 64, 3), False), ((8, 20, 256, 4), True)])
+def test_autoencoder_loss_and_grads(cuda, shape, alias):
+    n_dim, e_dim, hidden, layers = shape
+    n, e = 700, 3000
+    src, dst, ntype, etype = small_graph(n, e, n_dim, e_dim, seed=21, hub_deg=200, hub_out=150)
+    ref, mine = _model_pair(n_dim, e_dim, hidden, layers, cuda, alias=alias)
+    ref.eval()
+    mine.eval()   # dropout off on both sides; everything else is the training graph
+    gen = torch.Generator().manual_seed(5)
+    perm = torch.randperm(n, generator=gen)
+    pos_idx = torch.randperm(src.size, generator=gen)[:n]
+    og64 = to_ograph(src, dst, n, ntype, etype, n_dim, e_dim, torch.float64)
+    neg = O.uniform_negative_pairs(og64, n, seed=9)
+    ref64 = copy.deepcopy(ref).double()
+    lo, parts_o = ref64.compute_loss(og64, perm=perm, pos_idx=pos_idx, neg_pairs=neg, return_parts=True)
+    g = to_graph(src, dst, n, ntype, etype, n_dim, e_dim, cuda)
+    lm, parts_m = mine.compute_loss(g, perm=perm.to(cuda), pos_idx=pos_idx, neg_pairs=neg, return_parts=True)
+    assert abs(float(lm) - float(lo)) / abs(float(lo)) < 1e-4
+    assert abs(float(parts_m["sce"]) - float(parts_o["sce"])) / abs(float(parts_o["sce"])) < 1e-4
+    for hm, ho in zip(parts_m["hidden"], parts_o["hidden"]):
+        assert rel_err(hm, ho) < 1e-4
+    assert rel_err(parts_m["recon"], parts_o["recon"]) < 1e-4
+    lo.backward()
+    lm.backward()
+    for (k, po), (_, pm) in zip(ref64.named_parameters(), mine.named_parameters()):
+        if po.grad is None or float(po.grad.abs().max()) == 0.0:
+            continue
+        assert pm.grad is not None, k
+        assert rel_err(pm.grad, po.grad) < 5e-4, k
+
+
+def test_embed_matches_oracle_and_is_deterministic(cuda):
+    n_dim, e_dim = 11, 23
+    n, e = 900, 2600
+    src, dst, ntype, etype = small_graph(n, e, n_dim, e_dim, seed=33, hub_deg=400)
+    ref, mine = _model_pair(n_dim, e_dim, 64, 3, cuda, seed=1)
+    ref.eval()
+    mine.eval()
+    og = to_ograph(src, dst, n, ntype, etype, n_dim, e_dim, torch.float64)
+    g = to_graph(src, dst, n, ntype, etype, n_dim, e_dim, cuda)
+    with torch.no_grad():
+        eo = copy.deepcopy(ref).double().embed(og)
+        e1 = mine.embed(g)
+        e2 = mine.embed(g)
+    assert rel_err(e1, eo) < 1e-4
+    assert torch.equal(e1, e2)   # no atomics anywhere: bitwise reproducible
