@@ -1,0 +1,354 @@
+#!/usr/bin/env python3
+"""Benchmark of the MAGIC hot path on MI355X.
+
+One "step" = one training step of the masked-GAT auto-encoder (``compute_loss`` forward,
+backward, Adam update) on one E3-THEIA-shaped synthetic graph per GPU (N=700,000 nodes,
+E=3,000,000 edges, n_dim 5, e_dim 17, hidden 64, 3 layers, dropout on), inputs resident in
+HBM.  With N GPUs every rank steps on its own graph and the flat gradient buffer is
+all-reduced once per step (weak scaling).  ``value`` = edges of all ranks / step time.
+
+A second leg times the KNN outlier scorer (k=10, d=64, E3-Trace-sized train set of
+2,604,530 rows sharded over the ranks, a batch of queries per step) and is reported under
+``"knn"`` in the same JSON line.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
+       (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec
+F64_MFMA_PEAK_TF = 78.6    # MI355X fp64 matrix spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--workload", default="theia", help="synthetic shape name (magic_amd.synth.SHAPES)")
+    p.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debugging only)")
+    p.add_argument("--knn-train", type=int, default=2604530)
+    p.add_argument("--knn-queries", type=int, default=65536)
+    p.add_argument("--knn-steps", type=int, default=3)
+    p.add_argument("--no-knn", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def timed(fn, steps, world):
+    """barrier + synchronize on both sides, max over ranks (seconds for `steps` calls)."""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+# --------------------------------------------------------------------------- algorithmic bytes
+def layer_dims(n_dim, hidden, layers):
+    """(F, H, D) of every GAT layer of the auto-encoder: encoder layers then the decoder."""
+    dims = [(n_dim if l == 0 else hidden, 4, hidden // 4) for l in range(layers)]
+    dims.append((hidden, 1, n_dim))
+    return dims
+
+
+def kernel_bytes(kind, N, E_seg, H, C):
+    """Algorithmic HBM bytes of one launch (fp32 values, int32 ids, every tensor once)."""
+    if kind == "fwd":      # src id, edge type | gather eh, write a | gather hs row ; ptr, et, out row
+        return E_seg * (8 + 8 * H + 4 * C) + N * (4 + 4 * H + 4 * C)
+    if kind == "bwd_dst":  # src id, a, d_logit out, record | gather hs row ; ptr, d_et, d_out in, d_pre out
+        return E_seg * (8 + 8 * H + 4 * C) + N * (4 + 4 * H + 8 * C)
+    if kind == "bwd_src":  # dst id, position, a & d_logit | gather d_pre row ; ptr, d_eh, d_hs out
+        return E_seg * (12 + 8 * H + 4 * C) + N * (4 + 4 * H + 4 * C)
+    raise ValueError(kind)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from magic_amd import _lib, synth
+    from magic_amd.model.autoencoder import GMAEModel
+    from magic_amd.parallel import FlatGradAllReduce, broadcast_parameters
+    from magic_amd.utils.utils import set_random_seed
+
+    n, e, n_dim, e_dim, hidden, layers = synth.SHAPES[args.workload]
+    n, e = max(64, int(n * args.scale)), max(64, int(e * args.scale))
+    set_random_seed(0)
+    model = GMAEModel(n_dim, e_dim, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(dev)
+    broadcast_parameters(model)
+    model.train()
+    flat = FlatGradAllReduce(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+
+    g = synth.make_graph(n, e, n_dim, e_dim, seed=1004 + rank, attrs=False).to(dev)
+    g.structure.ensure_csr()
+    E = g.num_edges()
+    ntype, etype = g.ndata["type"], g.edata["type"]
+    e_attr = torch.nn.functional.one_hot(etype, e_dim).float()
+    g.edata["attr"] = e_attr
+    g.edge_types_csc()
+    total = args.warmup + 2 * args.steps + 2
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)
+    thr = min(10000, n)
+    perms = [torch.randperm(n, device=dev, generator=gen) for _ in range(total)]
+    pos = [torch.randint(0, E, (thr,), device=dev, generator=gen) for _ in range(total)]
+    from magic_amd.model.autoencoder import global_uniform_negative_sampling
+    negs = [global_uniform_negative_sampling(g, thr, generator=gen) for _ in range(total)]
+    counter = [0]
+
+    def step(_i):
+        k = counter[0] % total
+        counter[0] += 1
+        # fresh one-hot node attributes every step, as the reference's loaders produce them
+        g.ndata["attr"] = torch.nn.functional.one_hot(ntype, n_dim).float()
+        loss = model.compute_loss(g, perm=perms[k], pos_idx=pos[k], neg_pairs=negs[k])
+        flat.zero()
+        loss.backward()
+        flat.allreduce()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    flat.check_views()
+    dt = timed(step, args.steps, world)
+    ms_per_step = dt / args.steps * 1e3
+    edges_per_s = E * world * args.steps / dt
+
+    # ---- per-kernel timing over a second timed region (HIP events on the launch stream)
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    dt_prof = timed(step, args.steps, world)
+    _lib.prof_enable(False)
+    prof = _lib.prof_read(64)
+    _lib.prof_reset()
+
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        s = g.structure
+        deg_in = (s.in_ptr[1:] - s.in_ptr[:-1]).long()
+        deg_out = (s.out_ptr[1:] - s.out_ptr[:-1]).long()
+        from magic_amd.graph import LIGHT_MAX
+        e_light_in = int(deg_in[deg_in <= LIGHT_MAX].sum())
+        e_light_out = int(deg_out[deg_out <= LIGHT_MAX].sum())
+        dims = layer_dims(n_dim, hidden, layers)
+
+        def avg_bytes(kind, e_seg):
+            return sum(kernel_bytes(kind, n, e_seg, H, H * D) for _, H, D in dims) / len(dims)
+        algo = {"gat_fwd_light": avg_bytes("fwd", e_light_in),
+                "gat_fwd_heavy_agg": avg_bytes("fwd", E - e_light_in) - sum(
+                    n * (4 + 4 * H + 4 * H * D) for _, H, D in dims) / len(dims),
+                "gat_bwd_dst_light": avg_bytes("bwd_dst", e_light_in),
+                "gat_bwd_src_light": avg_bytes("bwd_src", e_light_out)}
+        for name, (cnt, tot_ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+            kernels[name] = {"launches": cnt, "avg_us": round(tot_ms / cnt * 1e3, 2),
+                             "total_ms_per_step": round(tot_ms / args.steps, 4)}
+        ranked = [k for k in sorted(prof, key=lambda k: -prof[k][1]) if k in algo]
+        if ranked:
+            name = ranked[0]
+            cnt, tot_ms = prof[name]
+            avg_s = tot_ms / cnt * 1e-3
+            achieved = algo[name] / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(args.workload, {}).get(name)
+                except Exception:
+                    traffic = None
+            roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": int(algo[name]), "avg_launch_us": round(avg_s * 1e6, 2),
+                        "launches_per_step": cnt // args.steps,
+                        "profiled_ms_per_step": round(dt_prof / args.steps * 1e3, 3)}
+
+    # ---- KNN leg
+    knn = None
+    if not args.no_knn:
+        knn = knn_leg(args, world, rank, dev)
+
+    # ---- CPU baselines (rank 0, N=1 only)
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = cpu_gat_baseline(args, n_dim, e_dim, hidden, layers)
+        if knn is not None:
+            knn["cpu_baseline"] = cpu_knn_baseline(args)
+
+    if rank == 0:
+        out = {
+            "metric": "masked-GAT fwd+bwd edges/sec", "value": round(edges_per_s, 1), "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"E3-THEIA-shaped full graph per GPU ({args.workload}): N={n} E={E} "
+                                   f"n_dim={n_dim} e_dim={e_dim} hidden={hidden} layers={layers}; "
+                                   "compute_loss fwd + bwd + Adam, dropout on, mask perms and sampled pairs "
+                                   "pre-generated", "parallelism": f"dp{world} (one graph per rank, "
+                                   "flat-buffer gradient all-reduce)" if world > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "knn": knn, "kernels": kernels,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def knn_leg(args, world, rank, dev):
+    """KNN scoring: train rows sharded over ranks, the same query batch on every rank."""
+    from magic_amd import _lib
+    from magic_amd.knn import ShardedNearestNeighbors, NearestNeighbors
+    nt, nq, d, k = args.knn_train, args.knn_queries, 64, 10
+    if args.scale != 1.0:
+        nt, nq = max(4096, int(nt * args.scale)), max(512, int(nq * args.scale))
+    per = (nt + world - 1) // world
+    lo, hi = min(rank * per, nt), min((rank + 1) * per, nt)
+    gen = torch.Generator(device=dev).manual_seed(1005)
+    centers = torch.randn(200, d, device=dev, generator=gen)
+    gen_r = torch.Generator(device=dev).manual_seed(2000 + rank)
+    train = centers[torch.randint(0, 200, (hi - lo,), device=dev, generator=gen_r)] + \
+        0.05 * torch.randn(hi - lo, d, device=dev, generator=gen_r)
+    gen_q = torch.Generator(device=dev).manual_seed(3000)
+    query = centers[torch.randint(0, 200, (nq,), device=dev, generator=gen_q)] + \
+        0.05 * torch.randn(nq, d, device=dev, generator=gen_q)
+    if world > 1:
+        nn_ = ShardedNearestNeighbors(k, device=dev)
+        nn_.fit(x_local=train, offset=lo)
+
+        def step(_i):
+            dd, _ = nn_.kneighbors_device(query, k)
+            return dd.mean(dim=1)
+    else:
+        nn_ = NearestNeighbors(k, device=dev).fit(train)
+
+        def step(_i):
+            dd, _ = nn_.kneighbors_device(query, k)
+            return dd.mean(dim=1)
+    step(0)
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    dt = timed(step, args.knn_steps, world)
+    _lib.prof_enable(False)
+    prof = _lib.prof_read(64)
+    _lib.prof_reset()
+    res = {"metric": "KNN-score queries/sec", "value": round(nq * args.knn_steps / dt, 1), "unit": "queries/s",
+           "ms_per_step": round(dt / args.knn_steps * 1e3, 3), "dtype": "f64",
+           "config": {"workload": f"E3-Trace-shaped: train {nt} x {d} f32 sharded over {world} rank(s), "
+                                  f"{nq} queries per step, k={k}"}}
+    name = "knn_topk_f64_mfma"
+    if name in prof:
+        cnt, tot_ms = prof[name]
+        flops = 2.0 * nq * (hi - lo) * d
+        ach = flops / (tot_ms / cnt * 1e-3) / 1e12
+        res["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": F64_MFMA_PEAK_TF,
+                           "unit": "TFLOP/s", "frac": round(ach / F64_MFMA_PEAK_TF, 4), "traffic": None,
+                           "avg_launch_ms": round(tot_ms / cnt, 3)}
+    return res
+
+
+def cpu_gat_baseline(args, n_dim, e_dim, hidden, layers):
+    """Torch-CPU restatement of the reference's DGL path (the oracle), same recipe, on a 1/10
+    scale graph of the same shape family."""
+    from magic_amd import synth
+    from oracle import gat_oracle as O
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(cores)
+    n0, e0 = synth.SHAPES[args.workload][:2]
+    scale = 0.1 * args.scale
+    n, e = max(64, int(n0 * scale)), max(64, int(e0 * scale))
+    g = synth.make_graph(n, e, n_dim, e_dim, seed=1004)
+    og = O.OGraph(g.edges()[0], g.edges()[1], n)
+    og.edata["attr"] = g.edata["attr"]
+    torch.manual_seed(0)
+    model = O.build_model(n_dim, e_dim, hidden, layers)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    thr = min(10000, n)
+
+    def step():
+        og.ndata["attr"] = torch.nn.functional.one_hot(g.ndata["type"], n_dim).float()
+        neg = O.uniform_negative_pairs(og, thr, seed=1)
+        loss = model.compute_loss(og, neg_pairs=neg, pos_idx=random.sample(range(e), thr))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    step()
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0 < 10 and reps < 50):
+        step()
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(e * reps / dt, 1), "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"torch-CPU restatement of the DGL path (oracle/gat_oracle.py), same recipe on a "
+                      f"{args.workload}-shaped graph at 1/10 scale (N={n}, E={e}), {reps} steps"}
+
+
+def cpu_knn_baseline(args):
+    """The reference's actual CPU path: sklearn NearestNeighbors(n_jobs=-1) (model/eval.py:294-311)
+    on a query sub-sample against the full train set (brute force is linear in Q)."""
+    nt, d, k = args.knn_train, 64, 10
+    if args.scale != 1.0:
+        nt = max(4096, int(nt * args.scale))
+    rng = np.random.default_rng(1005)
+    centers = rng.standard_normal((200, d)).astype(np.float32)
+    train = centers[rng.integers(0, 200, nt)] + 0.05 * rng.standard_normal((nt, d)).astype(np.float32)
+    nq = 2000
+    query = centers[rng.integers(0, 200, nq)] + 0.05 * rng.standard_normal((nq, d)).astype(np.float32)
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    try:
+        from sklearn.neighbors import NearestNeighbors
+        nbrs = NearestNeighbors(n_neighbors=k, n_jobs=-1).fit(train)
+        t0 = time.perf_counter()
+        nbrs.kneighbors(query[:200], n_neighbors=k)
+        t1 = time.perf_counter()
+        if (t1 - t0) * 10 > 40:
+            nq = 400
+        t0 = time.perf_counter()
+        nbrs.kneighbors(query[:nq], n_neighbors=k)
+        dt = time.perf_counter() - t0
+        kind, what = "reference", "sklearn.neighbors.NearestNeighbors(n_jobs=-1).kneighbors"
+    except ImportError:
+        from oracle import knn_oracle
+        nq = 200
+        t0 = time.perf_counter()
+        knn_oracle.exact_topk(train, query[:nq], k)
+        dt = time.perf_counter() - t0
+        kind, what = "port", "numpy float64 brute force (oracle/knn_oracle.py)"
+    return {"value": round(nq / dt, 1), "unit": "queries/s", "cores": cores, "kind": kind,
+            "sample": f"{what}: {nq} queries against the full {nt} x {d} train set, k={k}"}
+
+
+if __name__ == "__main__":
+    main()

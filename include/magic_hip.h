@@ -102,6 +102,20 @@ int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_scor
                    float *hs, int64_t ld_hs, float *score, float *res, int64_t ld_res,
                    void *stream);
 
+/* Backward of magic_proj_fwd (the adjoints torch autograd forms for nn.Linear at
+ * model/gat.py:284,:323 and model/autoencoder.py:237):
+ *   magic_proj_bwd_input : dX[N,out_dim] = dY[N,k_dim] . W[k_dim,out_dim] (+ add[N,out_dim])
+ *   magic_proj_bwd_weight: dW[M,F]       = dY[N,M]^T . X[N,F]   (fixed-order reduction over N)
+ */
+int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim,
+                         const float *dy, int64_t ld_dy, const float *w /* [k_dim,out_dim] */,
+                         const float *add /* optional */, int64_t ld_add,
+                         float *dx, int64_t ld_dx, void *stream);
+size_t magic_proj_bwd_weight_workspace_bytes(int64_t n_rows, int32_t m, int32_t f);
+int magic_proj_bwd_weight(int64_t n_rows, int32_t m, int32_t f,
+                          const float *dy, int64_t ld_dy, const float *x, int64_t ld_x,
+                          float *dw /* [m,f] */, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * One edge-feature-aware GAT layer, edge phase (model/gat.py:302-335):
  *   logit[e,h] = leaky_relu(eh[src e,h] + ee[e,h] + et[dst e,h])           (:302-307)
@@ -117,10 +131,10 @@ int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_scor
  * attn [E,H] in CSC order with the SIGN BIT set where the pre-activation logit was
  * negative (|attn| is the attention weight; backward needs the sign for leaky_relu').
  * ---------------------------------------------------------------------------------- */
-size_t magic_gat_fwd_workspace_bytes(int32_t n_chunks, int32_t n_heads, int32_t head_dim);
+size_t magic_gat_fwd_workspace_bytes(int32_t n_edges, int32_t n_chunks, int32_t n_heads, int32_t head_dim);
 int magic_gat_fwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t head_dim,
                   const magic_plan *in_plan /* host struct of device pointers */,
-                  const int32_t *in_src,
+                  const int32_t *in_src, const int32_t *in_dst /* [E] CSC order */,
                   const float *hs, int64_t ld_hs,
                   const float *eh, const float *et, int64_t ld_score /* row stride of eh and et */,
                   const float *ee_table, const int32_t *etype_csc, const float *ee_csc,

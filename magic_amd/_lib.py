@@ -37,8 +37,11 @@ SYMBOLS = {
     "magic_csr_build": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_proj_fwd": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp,
                                c_i64, c_vp]),
-    "magic_gat_fwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
-    "magic_gat_fwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp,
+    "magic_proj_bwd_input": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "magic_proj_bwd_weight_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
+    "magic_proj_bwd_weight": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "magic_gat_fwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "magic_gat_fwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, c_vp,
                               c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp,
                               c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_gat_bwd_workspace_bytes": (c_sz, [c_i32] * 7),
@@ -192,6 +195,43 @@ def proj_fwd(x: torch.Tensor, w: torch.Tensor, out_c: int, n_score: int, res_c: 
     return hs, score, res
 
 
+def proj_bwd_input(dy: torch.Tensor, w: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dX = dy @ w (+ add); dy [N,K] (unit inner stride), w [K,F]."""
+    lib = load()
+    assert dy.dim() == 2 and w.dim() == 2 and dy.shape[1] == w.shape[0]
+    if dy.stride(1) != 1:
+        dy = dy.contiguous()
+    w = w.contiguous()
+    if add is not None and add.stride(1) != 1:
+        add = add.contiguous()
+    N, K = dy.shape
+    F = w.shape[1]
+    dx = torch.empty(N, F, dtype=torch.float32, device=dy.device)
+    _check(lib.magic_proj_bwd_input(N, K, F, _dev(dy, torch.float32, "dy"), dy.stride(0), _dev(w, torch.float32, "w"),
+                                    _dev(add), add.stride(0) if add is not None else 0, _dev(dx), F, _stream()),
+           "magic_proj_bwd_input")
+    return dx
+
+
+def proj_bwd_weight(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW = dy.T @ x; dy [N,M], x [N,F] (unit inner strides) -> [M,F]."""
+    lib = load()
+    assert dy.dim() == 2 and x.dim() == 2 and dy.shape[0] == x.shape[0]
+    if dy.stride(1) != 1:
+        dy = dy.contiguous()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    N, M = dy.shape
+    F = x.shape[1]
+    dw = torch.empty(M, F, dtype=torch.float32, device=dy.device)
+    nbytes = lib.magic_proj_bwd_weight_workspace_bytes(N, M, F)
+    ws = workspace(nbytes, dy.device)
+    _check(lib.magic_proj_bwd_weight(N, M, F, _dev(dy, torch.float32, "dy"), dy.stride(0),
+                                     _dev(x, torch.float32, "x"), x.stride(0), _dev(dw), ws.data_ptr(), ws.numel(),
+                                     _stream()), "magic_proj_bwd_weight")
+    return dw
+
+
 # ------------------------------------------------------------------------------------- GAT
 def gat_fwd(struct, H: int, D: int, hs, eh, et, ee_table, etype_csc, ee_csc, slope: float, bias, res,
             prelu_w, want_pre: bool):
@@ -204,9 +244,9 @@ def gat_fwd(struct, H: int, D: int, hs, eh, et, ee_table, etype_csc, ee_csc, slo
     pre = torch.empty(N, Cc, dtype=torch.float32, device=dev) if want_pre else None
     attn = torch.empty(E, H, dtype=torch.float32, device=dev)
     plan = make_plan(struct.plan_in, LIGHT_MAX)
-    nbytes = lib.magic_gat_fwd_workspace_bytes(struct.plan_in.n_chunks, H, D)
+    nbytes = lib.magic_gat_fwd_workspace_bytes(E, struct.plan_in.n_chunks, H, D)
     ws = workspace(nbytes, dev)
-    _check(lib.magic_gat_fwd(N, E, H, D, C.byref(plan), _dev(struct.in_src),
+    _check(lib.magic_gat_fwd(N, E, H, D, C.byref(plan), _dev(struct.in_src), _dev(struct.in_dst),
                              _dev(hs, torch.float32, "hs"), hs.stride(0), _dev(eh, torch.float32, "eh"),
                              _dev(et, torch.float32, "et"), eh.stride(0), _dev(ee_table), _dev(etype_csc), _dev(ee_csc),
                              float(slope), _dev(bias), _dev(res), res.stride(0) if res is not None else 0,

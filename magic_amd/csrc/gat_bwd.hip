@@ -394,13 +394,20 @@ __global__ __launch_bounds__(256) void k_bwd_table_partial(BwdArgs a) {
     }
 }
 
+// one block per table entry: 256 threads add the block rows round robin, then a fixed tree
 __global__ __launch_bounds__(256) void k_bwd_table_final(BwdArgs a, int H) {
+    __shared__ float red[256];
     const int n = a.e_dim * H;
-    for (int o = threadIdx.x; o < n; o += 256) {
-        float t = 0.f;
-        for (int k = 0; k < a.grid_table; ++k) t += a.ws_table[(int64_t)k * n + o];
-        a.d_table[o] = t;
+    const int o = blockIdx.x;
+    float t = 0.f;
+    for (int k = threadIdx.x; k < a.grid_table; k += 256) t += a.ws_table[(int64_t)k * n + o];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) a.d_table[o] = red[0];
 }
 
 template <int H>
@@ -420,7 +427,7 @@ int launch_table(BwdArgs &a, hipStream_t stream) {
         MAGIC_LAUNCH("gat_bwd_table_partial", (k_bwd_table_partial<H, 32>), a.grid_table, 256, 0, stream, a);
     else
         return MAGIC_ERR_UNSUPPORTED;
-    MAGIC_LAUNCH("gat_bwd_table_final", k_bwd_table_final, 1, 256, 0, stream, a, H);
+    MAGIC_LAUNCH("gat_bwd_table_final", k_bwd_table_final, a.e_dim * H, 256, 0, stream, a, H);
     return MAGIC_OK;
 }
 

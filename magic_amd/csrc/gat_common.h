@@ -63,10 +63,28 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) {
     return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
 }
 
-// sum over the LPH lanes of one head; every lane of the head receives the total
+// Cross-lane exchange inside a row of 16 lanes through DPP (no LDS round trip):
+// 0xB1 = quad_perm[1,0,3,2], 0x4E = quad_perm[2,3,0,1], 0x141 = row_half_mirror (i <-> 7-i),
+// 0x140 = row_mirror (i <-> 15-i).  All lanes of a head group are active together, so every
+// source lane is valid.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// sum over the LPH (<= 16, aligned) lanes of one head; every lane receives the same bits
 template <int LPH> __device__ __forceinline__ float head_sum(float v) {
-#pragma unroll
-    for (int off = 1; off < LPH; off <<= 1) v += __shfl_xor(v, off, 64);
+    if (LPH >= 2) v += dpp_f<0xB1>(v);
+    if (LPH >= 4) v += dpp_f<0x4E>(v);
+    if (LPH >= 8) v += dpp_f<0x141>(v);
+    if (LPH >= 16) v += dpp_f<0x140>(v);
+    return v;
+}
+
+template <int LPH> __device__ __forceinline__ float head_max(float v) {
+    if (LPH >= 2) v = fmaxf(v, dpp_f<0xB1>(v));
+    if (LPH >= 4) v = fmaxf(v, dpp_f<0x4E>(v));
+    if (LPH >= 8) v = fmaxf(v, dpp_f<0x141>(v));
+    if (LPH >= 16) v = fmaxf(v, dpp_f<0x140>(v));
     return v;
 }
 

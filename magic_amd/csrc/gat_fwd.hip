@@ -1,7 +1,15 @@
 // GAT layer, edge phase, forward: attention logits -> leaky ReLU -> per-destination
 // softmax -> weighted aggregation of source rows -> bias + residual (+ PReLU).
 // HBM-bound: per edge one gathered hs row (4*H*D bytes) dominates; everything else is
-// streamed once in CSC order.  No atomics; every reduction has a fixed order.
+// streamed in CSC order.  No atomics; every reduction has a fixed order.
+//
+// Launch sequence per layer:
+//   gat_edge_logits       one thread per edge: x[e,:] = (eh[src e] + ee[e]) + et[dst e]
+//                         (the only place that gathers eh; fully edge-parallel)
+//   gat_fwd_light         one lane group per destination with <= light_max in-edges:
+//                         max / sum-exp over the streamed logits, then the row gather
+//   gat_fwd_heavy_*       longer segments in chunks of one wave each (stats, aggregate,
+//                         finish), combined in chunk order
 #include "gat_common.h"
 
 namespace magic {
@@ -10,6 +18,7 @@ struct FwdArgs {
     int N, E;
     PlanDev plan;
     const int32_t *src;  // [E] CSC order
+    const int32_t *dst;  // [E] CSC order
     const float *hs;
     int64_t ld_hs;
     const float *eh;  // [N,ld_s] head scores of the node as a source
@@ -27,14 +36,24 @@ struct FwdArgs {
     int64_t ld_out;
     float *pre;   // [N,C] or null
     float *attn;  // [E,H]
+    float *x;         // [E,H] raw logits (workspace)
     float *ws_stats;  // [n_chunks,H,2]
     float *ws_acc;    // [n_chunks,C]
 };
 
 template <int H, bool TABLE>
-__device__ __forceinline__ float raw_logit(const FwdArgs &a, int i, int u, int h, float etv) {
-    float ee = TABLE ? a.ee_table[a.etype[i] * H + h] : a.ee[(int64_t)i * H + h];
-    return (a.eh[(int64_t)u * a.ld_s + h] + ee) + etv;
+__global__ __launch_bounds__(256) void k_edge_logits(FwdArgs a) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.E; i += gridDim.x * 256) {
+        const int u = a.src[i], v = a.dst[i];
+        const float *ehp = a.eh + (int64_t)u * a.ld_s;
+        const float *etp = a.et + (int64_t)v * a.ld_s;
+        const float *eep = TABLE ? a.ee_table + a.etype[i] * H : a.ee + (int64_t)i * H;
+        float r[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) r[h] = (ehp[h] + eep[h]) + etp[h];
+#pragma unroll
+        for (int h = 0; h < H; ++h) a.x[(int64_t)i * H + h] = r[h];
+    }
 }
 
 template <int H, int LPH>
@@ -53,50 +72,49 @@ __device__ __forceinline__ void epilogue(const FwdArgs &a, int v, int g, float4 
     st4(a.out + (int64_t)v * a.ld_out + g * 4, acc);
 }
 
-// One lane group (G lanes) per destination node; segments longer than light_max are left
-// to the heavy kernels.  Three sweeps over the segment: max, sum of exp, aggregation; the
-// first two touch only the H-float score rows (cache resident), the third gathers hs rows.
-template <int H, int LPH, bool TABLE>
+// One lane group (G lanes) per destination node.  The LPH lanes of a head split the
+// segment for the max and the sum of exponentials (combined with DPP), then every lane
+// walks all edges for the aggregation of its 4 channels.
+template <int H, int LPH>
 __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
     constexpr int G = H * LPH;
     constexpr int NPB = 256 / G;
     const int g = threadIdx.x % G;
     const int h = g / LPH;
+    const int q = g % LPH;
     const int slot = threadIdx.x / G;
-    const bool writer = (g % LPH) == 0;
+    const bool writer = q == 0;
     for (int v = blockIdx.x * NPB + slot; v < a.N; v += gridDim.x * NPB) {
         const int b = a.plan.ptr[v], e = a.plan.ptr[v + 1];
         if (e - b > a.plan.light_max) continue;
-        const float etv = a.et[(int64_t)v * a.ld_s + h];
         float m = -INFINITY;
-        for (int i = b; i < e; ++i) m = fmaxf(m, leaky(raw_logit<H, TABLE>(a, i, a.src[i], h, etv), a.slope));
+        for (int i = b + q; i < e; i += LPH) m = fmaxf(m, leaky(a.x[(int64_t)i * H + h], a.slope));
+        m = head_max<LPH>(m);
         float s = 0.f;
-        for (int i = b; i < e; ++i) s += expf(leaky(raw_logit<H, TABLE>(a, i, a.src[i], h, etv), a.slope) - m);
+        for (int i = b + q; i < e; i += LPH) s += __expf(leaky(a.x[(int64_t)i * H + h], a.slope) - m);
+        s = head_sum<LPH>(s);
         const float inv = 1.f / s;
         float4 acc = f4zero();
         int i = b;
         for (; i + 4 <= e; i += 4) {
-            int u[4];
-            float w[4];
             float4 r[4];
+            float w[4], x[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) u[j] = a.src[i + j];
+            for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)a.src[i + j] * a.ld_hs + g * 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)u[j] * a.ld_hs + g * 4);
+            for (int j = 0; j < 4; ++j) x[j] = a.x[(int64_t)(i + j) * H + h];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float x = raw_logit<H, TABLE>(a, i + j, u[j], h, etv);
-                w[j] = expf(leaky(x, a.slope) - m) * inv;
-                if (writer) a.attn[(int64_t)(i + j) * H + h] = pack_attn(w[j], x);
+                w[j] = __expf(leaky(x[j], a.slope) - m) * inv;
+                if (writer) a.attn[(int64_t)(i + j) * H + h] = pack_attn(w[j], x[j]);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) fma4(acc, w[j], r[j]);
         }
         for (; i < e; ++i) {
-            int u = a.src[i];
-            float4 r = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
-            float x = raw_logit<H, TABLE>(a, i, u, h, etv);
-            float w = expf(leaky(x, a.slope) - m) * inv;
+            float4 r = ld4(a.hs + (int64_t)a.src[i] * a.ld_hs + g * 4);
+            float x = a.x[(int64_t)i * H + h];
+            float w = __expf(leaky(x, a.slope) - m) * inv;
             if (writer) a.attn[(int64_t)i * H + h] = pack_attn(w, x);
             fma4(acc, w, r);
         }
@@ -106,27 +124,21 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
 
 // Heavy segments, step 1: one wave per chunk, one lane per edge; per-chunk (max, sum exp)
 // for every head.
-template <int H, bool TABLE>
+template <int H>
 __global__ __launch_bounds__(256) void k_fwd_heavy_stats(FwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= a.plan.n_chunks) return;
-    const int v = a.plan.heavy_node[a.plan.chunk_node[c]];
     const int beg = a.plan.chunk_beg[c], end = a.plan.chunk_end[c];
-    float m[H], s[H], etv[H];
+    float m[H], s[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         m[h] = -INFINITY;
         s[h] = 0.f;
-        etv[h] = a.et[(int64_t)v * a.ld_s + h];
     }
     for (int i = beg + lane; i < end; i += 64) {
-        const int u = a.src[i];
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            float l = leaky(raw_logit<H, TABLE>(a, i, u, h, etv[h]), a.slope);
-            ms_fold(m[h], s[h], l, 1.f);
-        }
+        for (int h = 0; h < H; ++h) ms_fold(m[h], s[h], leaky(a.x[(int64_t)i * H + h], a.slope), 1.f);
     }
 #pragma unroll
     for (int h = 0; h < H; ++h) {
@@ -169,7 +181,7 @@ __device__ __forceinline__ void node_stats(const FwdArgs &a, int slot, int lane,
 
 // Heavy segments, step 2: one wave per chunk; the 64/G lane groups take edges round robin,
 // write the attention weights and a partial aggregate per chunk.
-template <int H, int LPH, bool TABLE>
+template <int H, int LPH>
 __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
     constexpr int G = H * LPH;
     constexpr int NSG = 64 / G;
@@ -178,7 +190,6 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= a.plan.n_chunks) return;
     const int slot = a.plan.chunk_node[c];
-    const int v = a.plan.heavy_node[slot];
     const int beg = a.plan.chunk_beg[c], end = a.plan.chunk_end[c];
     float mm[H], ss[H];
     node_stats<H>(a, slot, lane, mm, ss);
@@ -191,32 +202,28 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
             s = ss[k];
         }
     const float inv = 1.f / s;
-    const float etv = a.et[(int64_t)v * a.ld_s + h];
     const bool writer = (g % LPH) == 0;
     float4 acc = f4zero();
     int i = beg + sg;
     for (; i + 3 * NSG < end; i += 4 * NSG) {
-        int u[4];
         float4 r[4];
-        float w[4];
+        float w[4], x[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) u[j] = a.src[i + j * NSG];
+        for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)a.src[i + j * NSG] * a.ld_hs + g * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)u[j] * a.ld_hs + g * 4);
+        for (int j = 0; j < 4; ++j) x[j] = a.x[(int64_t)(i + j * NSG) * H + h];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float x = raw_logit<H, TABLE>(a, i + j * NSG, u[j], h, etv);
-            w[j] = expf(leaky(x, a.slope) - m) * inv;
-            if (writer) a.attn[(int64_t)(i + j * NSG) * H + h] = pack_attn(w[j], x);
+            w[j] = __expf(leaky(x[j], a.slope) - m) * inv;
+            if (writer) a.attn[(int64_t)(i + j * NSG) * H + h] = pack_attn(w[j], x[j]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) fma4(acc, w[j], r[j]);
     }
     for (; i < end; i += NSG) {
-        int u = a.src[i];
-        float4 r = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
-        float x = raw_logit<H, TABLE>(a, i, u, h, etv);
-        float w = expf(leaky(x, a.slope) - m) * inv;
+        float4 r = ld4(a.hs + (int64_t)a.src[i] * a.ld_hs + g * 4);
+        float x = a.x[(int64_t)i * H + h];
+        float w = __expf(leaky(x, a.slope) - m) * inv;
         if (writer) a.attn[(int64_t)i * H + h] = pack_attn(w, x);
         fma4(acc, w, r);
     }
@@ -245,18 +252,25 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_finish(FwdArgs a) {
     }
 }
 
-template <int H, int LPH, bool TABLE>
-int launch_fwd(const FwdArgs &a, hipStream_t stream) {
+template <int H, int LPH>
+int launch_fwd(const FwdArgs &a, bool table, hipStream_t stream) {
     constexpr int G = H * LPH;
     constexpr int NPB = 256 / G;
+    if (a.E > 0) {
+        int grid = stride_grid(a.E, 256, 256 * 32);
+        if (table)
+            MAGIC_LAUNCH("gat_edge_logits", (k_edge_logits<H, true>), grid, 256, 0, stream, a);
+        else
+            MAGIC_LAUNCH("gat_edge_logits", (k_edge_logits<H, false>), grid, 256, 0, stream, a);
+    }
     if (a.N > 0) {
-        int grid = stride_grid(a.N, NPB, 256 * 16);
-        MAGIC_LAUNCH("gat_fwd_light", (k_fwd_light<H, LPH, TABLE>), grid, 256, 0, stream, a);
+        int grid = stride_grid(a.N, NPB, 256 * 32);
+        MAGIC_LAUNCH("gat_fwd_light", (k_fwd_light<H, LPH>), grid, 256, 0, stream, a);
     }
     if (a.plan.n_chunks > 0) {
         int cgrid = (a.plan.n_chunks + 3) / 4;
-        MAGIC_LAUNCH("gat_fwd_heavy_stats", (k_fwd_heavy_stats<H, TABLE>), cgrid, 256, 0, stream, a);
-        MAGIC_LAUNCH("gat_fwd_heavy_agg", (k_fwd_heavy_agg<H, LPH, TABLE>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH("gat_fwd_heavy_stats", (k_fwd_heavy_stats<H>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH("gat_fwd_heavy_agg", (k_fwd_heavy_agg<H, LPH>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_fwd_heavy_finish", (k_fwd_heavy_finish<H, LPH>), a.plan.n_heavy, 256, 0, stream, a);
     }
     return launch_status();
@@ -266,24 +280,26 @@ int launch_fwd(const FwdArgs &a, hipStream_t stream) {
 
 extern "C" {
 
-size_t magic_gat_fwd_workspace_bytes(int32_t n_chunks, int32_t H, int32_t D) {
-    if (n_chunks <= 0) return 256;
-    return magic::align_up((size_t)n_chunks * H * 2 * sizeof(float)) +
-           magic::align_up((size_t)n_chunks * H * D * sizeof(float)) + 256;
+size_t magic_gat_fwd_workspace_bytes(int32_t n_edges, int32_t n_chunks, int32_t H, int32_t D) {
+    size_t b = magic::align_up((size_t)(n_edges > 0 ? n_edges : 1) * H * sizeof(float));
+    if (n_chunks > 0)
+        b += magic::align_up((size_t)n_chunks * H * 2 * sizeof(float)) +
+             magic::align_up((size_t)n_chunks * H * D * sizeof(float));
+    return b + 256;
 }
 
 int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_src,
-                  const float *hs, int64_t ld_hs, const float *eh, const float *et, int64_t ld_score,
-                  const float *ee_table,
-                  const int32_t *etype_csc, const float *ee_csc, float slope, const float *bias,
-                  const float *res, int64_t ld_res, const float *prelu_w, float *out, int64_t ld_out,
-                  float *pre, float *attn, void *workspace, size_t workspace_bytes, void *stream_) {
+                  const int32_t *in_dst, const float *hs, int64_t ld_hs, const float *eh, const float *et,
+                  int64_t ld_score, const float *ee_table, const int32_t *etype_csc, const float *ee_csc,
+                  float slope, const float *bias, const float *res, int64_t ld_res, const float *prelu_w,
+                  float *out, int64_t ld_out, float *pre, float *attn, void *workspace, size_t workspace_bytes,
+                  void *stream_) {
     using namespace magic;
     if (N < 0 || E < 0 || H <= 0 || D <= 0) return MAGIC_ERR_INVALID_ARG;
     if (!shape_supported(H, D)) return MAGIC_ERR_UNSUPPORTED;
     if (N == 0) return MAGIC_OK;
     if (!plan_valid(in_plan) || !hs || !eh || !et || !out) return MAGIC_ERR_INVALID_ARG;
-    if (E > 0 && (!in_src || !attn)) return MAGIC_ERR_INVALID_ARG;
+    if (E > 0 && (!in_src || !in_dst || !attn)) return MAGIC_ERR_INVALID_ARG;
     const bool table = ee_table != nullptr;
     if (E > 0 && table && !etype_csc) return MAGIC_ERR_INVALID_ARG;
     if (E > 0 && !table && !ee_csc) return MAGIC_ERR_INVALID_ARG;
@@ -295,6 +311,7 @@ int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     a.E = E;
     a.plan = plan_dev(in_plan);
     a.src = in_src;
+    a.dst = in_dst;
     a.hs = hs;
     a.ld_hs = ld_hs;
     a.eh = eh;
@@ -313,17 +330,17 @@ int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     a.pre = pre;
     a.attn = attn;
     a.ws_stats = a.ws_acc = nullptr;
+    Arena ar(workspace, workspace_bytes);
+    a.x = ar.take<float>((size_t)(E > 0 ? E : 1) * H);
     if (a.plan.n_chunks > 0) {
-        Arena ar(workspace, workspace_bytes);
         a.ws_stats = ar.take<float>((size_t)a.plan.n_chunks * H * 2);
         a.ws_acc = ar.take<float>((size_t)a.plan.n_chunks * C);
-        if (!ar.ok() || !a.ws_stats || !a.ws_acc) return MAGIC_ERR_WORKSPACE;
     }
+    if (!ar.ok() || !a.x) return MAGIC_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int lph = D / 4;
-#define X(h, l)                                                              \
-    if (H == h && lph == l)                                                  \
-        return table ? launch_fwd<h, l, true>(a, stream) : launch_fwd<h, l, false>(a, stream);
+#define X(h, l) \
+    if (H == h && lph == l) return launch_fwd<h, l>(a, table, stream);
     MAGIC_GAT_SHAPES(X)
 #undef X
     return MAGIC_ERR_UNSUPPORTED;

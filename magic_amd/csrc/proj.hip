@@ -25,6 +25,11 @@ struct ProjArgs {
     const float *x;
     int64_t ld_x;
     const float *w;
+    int64_t w_rs, w_cs;  // element (row r, k) of the weight = w[r * w_rs + k * w_cs]
+    int col0;            // first output column of this launch (wide outputs take several)
+    const float *add;    // optional [N, ld_add] added to the hs columns
+    int64_t ld_add;
+    const char *name;
     float *hs;
     int64_t ld_hs;
     float *score;
@@ -45,7 +50,8 @@ __global__ __launch_bounds__(256) void k_proj(ProjArgs a) {
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-    const bool vec = (a.F % 4 == 0) && (a.ld_x % 4 == 0) && ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0);
+    const bool vec = (a.F % 4 == 0) && (a.ld_x % 4 == 0) && ((uintptr_t)a.x % 16 == 0);
+    const bool wvec = (a.F % 4 == 0) && a.w_cs == 1 && (a.w_rs % 4 == 0) && ((uintptr_t)a.w % 16 == 0);
 
     for (int k0 = 0; k0 < a.F; k0 += KC) {
         __syncthreads();
@@ -71,15 +77,15 @@ __global__ __launch_bounds__(256) void k_proj(ProjArgs a) {
         for (int idx = tid; idx < NCT * 32 * (KC / 4); idx += 256) {
             int r = idx / (KC / 4), c4 = (idx % (KC / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < a.M) {
-                const float *p = a.w + (int64_t)r * a.F + k0 + c4;
-                if (vec && k0 + c4 + 3 < a.F) {
+            if (a.col0 + r < a.M) {
+                const float *p = a.w + (int64_t)(a.col0 + r) * a.w_rs + (int64_t)(k0 + c4) * a.w_cs;
+                if (wvec && k0 + c4 + 3 < a.F) {
                     v = *reinterpret_cast<const float4 *>(p);
                 } else {
                     if (k0 + c4 + 0 < a.F) v.x = p[0];
-                    if (k0 + c4 + 1 < a.F) v.y = p[1];
-                    if (k0 + c4 + 2 < a.F) v.z = p[2];
-                    if (k0 + c4 + 3 < a.F) v.w = p[3];
+                    if (k0 + c4 + 1 < a.F) v.y = p[a.w_cs];
+                    if (k0 + c4 + 2 < a.F) v.z = p[2 * a.w_cs];
+                    if (k0 + c4 + 3 < a.F) v.w = p[3 * a.w_cs];
                 }
             }
             *reinterpret_cast<float4 *>(ws + r * LDS_LD + c4) = v;
@@ -116,13 +122,14 @@ __global__ __launch_bounds__(256) void k_proj(ProjArgs a) {
     // epilogue: route columns
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        const int col = ct * 32 + lr;
+        const int col = a.col0 + ct * 32 + lr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
             if (row >= a.n) continue;
-            const float v = acc[ct][r];
+            float v = acc[ct][r];
             if (col < a.C) {
+                if (a.add) v += a.add[row * a.ld_add + col];
                 a.hs[row * a.ld_hs + col] = v;
             } else if (col < a.C + a.NS) {
                 a.score[row * a.NS + (col - a.C)] = v;
@@ -141,9 +148,11 @@ template <int NCT> int launch(const ProjArgs &a, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void *)k_proj<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         attr_set = true;
     }
-    MAGIC_LAUNCH("proj_fwd_mfma_f32", (k_proj<NCT>), grid, 256, sh, stream, a);
+    MAGIC_LAUNCH(a.name, (k_proj<NCT>), grid, 256, sh, stream, a);
     return magic::launch_status();
 }
+
+int dispatch(const ProjArgs &a, hipStream_t stream);
 
 }  // namespace
 
@@ -166,20 +175,53 @@ int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_scor
     a.x = x;
     a.ld_x = ld_x;
     a.w = w;
+    a.w_rs = in_dim;
+    a.w_cs = 1;
+    a.add = nullptr;
+    a.ld_add = 0;
+    a.name = "proj_fwd_mfma_f32";
     a.hs = hs;
     a.ld_hs = ld_hs;
     a.score = score;
     a.res = res;
     a.ld_res = ld_res;
     hipStream_t stream = (hipStream_t)stream_;
-    if ((a.M + 31) / 32 > 10 && res_c > 0) {
-        // too many accumulator tiles for one pass: residual columns in a second pass
-        int st = magic_proj_fwd(n_rows, in_dim, out_c, n_score, 0, x, ld_x, w, hs, ld_hs, score, nullptr, 0, stream_);
-        if (st != MAGIC_OK) return st;
-        return magic_proj_fwd(n_rows, in_dim, res_c, 0, 0, x, ld_x, w + (int64_t)(out_c + n_score) * in_dim, res,
-                              ld_res, nullptr, nullptr, 0, stream_);
-    }
-    const int nct = (a.M + 31) / 32;
+    return dispatch(a, stream);
+}
+
+int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim, const float *dy, int64_t ld_dy,
+                         const float *w, const float *add, int64_t ld_add, float *dx, int64_t ld_dx,
+                         void *stream_) {
+    if (n_rows < 0 || k_dim <= 0 || out_dim <= 0) return MAGIC_ERR_INVALID_ARG;
+    if (n_rows == 0) return MAGIC_OK;
+    if (!dy || !w || !dx || ld_dy < k_dim || ld_dx < out_dim || (add && ld_add < out_dim)) return MAGIC_ERR_INVALID_ARG;
+    ProjArgs a;
+    a.n = n_rows;
+    a.F = k_dim;       // reduction runs over the columns of dY
+    a.C = out_dim;
+    a.NS = 0;
+    a.RC = 0;
+    a.M = out_dim;
+    a.x = dy;
+    a.ld_x = ld_dy;
+    a.w = w;           // [k_dim, out_dim] row-major, read transposed
+    a.w_rs = 1;
+    a.w_cs = out_dim;
+    a.add = add;
+    a.ld_add = ld_add;
+    a.name = "proj_bwd_input_mfma_f32";
+    a.hs = dx;
+    a.ld_hs = ld_dx;
+    a.score = nullptr;
+    a.res = nullptr;
+    a.ld_res = 0;
+    return dispatch(a, (hipStream_t)stream_);
+}
+
+}  // extern "C"
+
+namespace {
+int dispatch_one(const ProjArgs &a, int nct, hipStream_t stream) {
     switch (nct) {
         case 1: return launch<1>(a, stream);
         case 2: return launch<2>(a, stream);
@@ -191,8 +233,23 @@ int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_scor
         case 8: return launch<8>(a, stream);
         case 9: return launch<9>(a, stream);
         case 10: return launch<10>(a, stream);
-        default: return MAGIC_ERR_UNSUPPORTED;  // M > 320: caller falls back to a library GEMM
+        default: return MAGIC_ERR_UNSUPPORTED;
     }
 }
 
-}  // extern "C"
+// up to 10 column tiles (320 outputs) per launch; wider outputs take several launches of 8
+int dispatch(const ProjArgs &a0, hipStream_t stream) {
+    ProjArgs a = a0;
+    const int tiles = (a.M + 31) / 32;
+    if (tiles <= 10) {
+        a.col0 = 0;
+        return dispatch_one(a, tiles, stream);
+    }
+    for (int t0 = 0; t0 < tiles; t0 += 8) {
+        a.col0 = t0 * 32;
+        int st = dispatch_one(a, tiles - t0 < 8 ? tiles - t0 : 8, stream);
+        if (st != MAGIC_OK) return st;
+    }
+    return MAGIC_OK;
+}
+}  // namespace

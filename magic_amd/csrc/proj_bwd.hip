@@ -1,0 +1,215 @@
+// Weight gradient of the node projection:  dW[M,F] = dY[N,M]^T . X[N,F]  in exact fp32 on the
+// matrix cores.  The reduction runs over the N nodes (hundreds of thousands), the output is
+// tiny, so the kernel streams both inputs once: every MFMA operand is one coalesced
+// 128-byte row segment read straight from HBM (lane l supplies dY[row][m0 + (l&31)] and
+// X[row][f0 + (l&31)], lane half l>>5 selects which of the two rows of the k-step), no LDS
+// staging.  Each wave owns a strip of rows and a register tile of the output; the waves of a
+// block are summed through LDS in wave order and the block partials by a second launch in
+// block order (bitwise reproducible, no atomics).
+#include "common.h"
+
+namespace {
+
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+struct DwArgs {
+    int64_t n;
+    int M, F;
+    const float *dy;
+    int64_t ld_dy;
+    const float *x;
+    int64_t ld_x;
+    float *partial;  // [n_strips][n_groups][MT*FT][16][64]
+    float *dw;       // [M,F]
+    int n_strips;
+    int64_t rows_per_wave;  // even
+    int mg, fg;             // output tile groups along M and F
+};
+
+template <int MT, int FT>
+__global__ __launch_bounds__(256) void k_proj_dw(DwArgs a) {
+    extern __shared__ float lds[];  // 3 waves x MT*FT*16*64 floats
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hf = lane >> 5, li = lane & 31;
+    const int strip = blockIdx.x;
+    const int grp = blockIdx.y;
+    const int m0 = (grp / a.fg) * MT * 32, f0 = (grp % a.fg) * FT * 32;
+    float16_t acc[MT][FT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][ft][r] = 0.f;
+    const int64_t r_beg = ((int64_t)strip * 4 + wave) * a.rows_per_wave;
+    int64_t r_end = r_beg + a.rows_per_wave;
+    if (r_end > a.n) r_end = a.n;
+    bool mok[MT], fok[FT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) mok[mt] = m0 + mt * 32 + li < a.M;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) fok[ft] = f0 + ft * 32 + li < a.F;
+    constexpr int U = 4;  // k-steps in flight
+    for (int64_t r = r_beg; r < r_end; r += 2 * U) {
+        float av[U][MT], bv[U][FT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = r + 2 * u + hf;
+            const bool rok = row < r_end;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                av[u][mt] = (rok && mok[mt]) ? a.dy[row * a.ld_dy + m0 + mt * 32 + li] : 0.f;
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft)
+                bv[u][ft] = (rok && fok[ft]) ? a.x[row * a.ld_x + f0 + ft * 32 + li] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft)
+                    acc[mt][ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt], bv[u][ft], acc[mt][ft], 0, 0, 0);
+    }
+    // waves 1..3 park their tiles in LDS; wave 0 adds them in wave order and writes the block partial
+    constexpr int TILE = MT * FT * 16 * 64;
+    if (wave > 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lds[(wave - 1) * TILE + ((mt * FT + ft) * 16 + r) * 64 + lane] = acc[mt][ft][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *out = a.partial + ((int64_t)strip * gridDim.y + grp) * TILE;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = ((mt * FT + ft) * 16 + r) * 64 + lane;
+                    float v = acc[mt][ft][r];
+                    v += lds[o];
+                    v += lds[TILE + o];
+                    v += lds[2 * TILE + o];
+                    out[o] = v;
+                }
+    }
+}
+
+// dW[i][j] = sum over strips (in strip order, 8 interleaved running sums folded in a fixed
+// order) of the partial tiles; one thread per output element.
+template <int MT, int FT>
+__global__ __launch_bounds__(256) void k_proj_dw_reduce(DwArgs a) {
+    constexpr int TILE = MT * FT * 16 * 64;
+    const int grp = blockIdx.y;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= TILE) return;
+    const int lane = o & 63, r = (o >> 6) & 15, t = o >> 10;
+    const int mt = t / FT, ft = t % FT;
+    const int m0 = (grp / a.fg) * MT * 32, f0 = (grp % a.fg) * FT * 32;
+    const int i = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int j = f0 + ft * 32 + (lane & 31);
+    if (i >= a.M || j >= a.F) return;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float *p = a.partial + (int64_t)grp * TILE + o;
+    const int64_t stride = (int64_t)gridDim.y * TILE;
+    int k = 0;
+    for (; k + 8 <= a.n_strips; k += 8)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += p[(int64_t)(k + u) * stride];
+    for (; k < a.n_strips; ++k) s[0] += p[(int64_t)k * stride];
+    a.dw[(int64_t)i * a.F + j] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+struct DwPlan {
+    int mt, ft, mg, fg, n_strips;
+    int64_t rows_per_wave;
+    size_t partial_floats;
+};
+
+DwPlan plan_dw(int64_t n, int M, int F) {
+    DwPlan p;
+    int mtiles = (M + 31) / 32, ftiles = (F + 31) / 32;
+    p.ft = ftiles >= 2 ? 2 : 1;
+    p.mt = mtiles >= 3 ? 3 : mtiles;
+    p.mg = (mtiles + p.mt - 1) / p.mt;
+    p.fg = (ftiles + p.ft - 1) / p.ft;
+    int groups = p.mg * p.fg;
+    int strips = 512 / groups;
+    if (strips < 8) strips = 8;
+    if (strips > 256) strips = 256;
+    int64_t waves = (int64_t)strips * 4;
+    int64_t rpw = (n + waves - 1) / waves;
+    rpw = (rpw + 7) / 8 * 8;  // whole unrolled iterations
+    if (rpw < 8) rpw = 8;
+    p.rows_per_wave = rpw;
+    p.n_strips = (int)((n + rpw * 4 - 1) / (rpw * 4));
+    if (p.n_strips < 1) p.n_strips = 1;
+    p.partial_floats = (size_t)p.n_strips * groups * p.mt * p.ft * 16 * 64;
+    return p;
+}
+
+template <int MT, int FT> int run_dw(DwArgs &a, const DwPlan &p, hipStream_t stream) {
+    constexpr int TILE = MT * FT * 16 * 64;
+    size_t sh = (size_t)3 * TILE * sizeof(float);
+    static bool attr_set = false;
+    if (sh > 48 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_proj_dw<MT, FT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        attr_set = true;
+    }
+    dim3 grid(p.n_strips, p.mg * p.fg);
+    MAGIC_LAUNCH("proj_bwd_weight_mfma_f32", (k_proj_dw<MT, FT>), grid, 256, sh, stream, a);
+    dim3 rgrid((TILE + 255) / 256, p.mg * p.fg);
+    MAGIC_LAUNCH("proj_bwd_weight_reduce", (k_proj_dw_reduce<MT, FT>), rgrid, 256, 0, stream, a);
+    return magic::launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t magic_proj_bwd_weight_workspace_bytes(int64_t n_rows, int32_t m, int32_t f) {
+    if (n_rows <= 0 || m <= 0 || f <= 0) return 256;
+    return magic::align_up(plan_dw(n_rows, m, f).partial_floats * sizeof(float)) + 256;
+}
+
+int magic_proj_bwd_weight(int64_t n_rows, int32_t m, int32_t f, const float *dy, int64_t ld_dy, const float *x,
+                          int64_t ld_x, float *dw, void *workspace, size_t workspace_bytes, void *stream_) {
+    if (n_rows < 0 || m <= 0 || f <= 0) return MAGIC_ERR_INVALID_ARG;
+    if (!dw) return MAGIC_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows == 0) {
+        if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)m * f, stream) != hipSuccess) return MAGIC_ERR_RUNTIME;
+        return MAGIC_OK;
+    }
+    if (!dy || !x || ld_dy < m || ld_x < f) return MAGIC_ERR_INVALID_ARG;
+    DwPlan p = plan_dw(n_rows, m, f);
+    magic::Arena ar(workspace, workspace_bytes);
+    DwArgs a;
+    a.n = n_rows;
+    a.M = m;
+    a.F = f;
+    a.dy = dy;
+    a.ld_dy = ld_dy;
+    a.x = x;
+    a.ld_x = ld_x;
+    a.partial = ar.take<float>(p.partial_floats);
+    if (!ar.ok() || !a.partial) return MAGIC_ERR_WORKSPACE;
+    a.dw = dw;
+    a.n_strips = p.n_strips;
+    a.rows_per_wave = p.rows_per_wave;
+    a.mg = p.mg;
+    a.fg = p.fg;
+    if (p.mt == 3 && p.ft == 2) return run_dw<3, 2>(a, p, stream);
+    if (p.mt == 3 && p.ft == 1) return run_dw<3, 1>(a, p, stream);
+    if (p.mt == 2 && p.ft == 2) return run_dw<2, 2>(a, p, stream);
+    if (p.mt == 2 && p.ft == 1) return run_dw<2, 1>(a, p, stream);
+    if (p.mt == 1 && p.ft == 2) return run_dw<1, 2>(a, p, stream);
+    return run_dw<1, 1>(a, p, stream);
+}
+
+}  // extern "C"

@@ -98,7 +98,7 @@ class Structure:
         self.num_nodes = int(num_nodes)
         self.num_edges = int(src.numel())
         # CSC: edges sorted by destination (ties keep ascending edge id)
-        self.in_ptr = self.in_src = self.in_eid = None
+        self.in_ptr = self.in_src = self.in_eid = self.in_dst = None
         # CSR: edges sorted by source; out_pos = position of that edge in CSC order
         self.out_ptr = self.out_dst = self.out_eid = self.out_pos = None
         self.plan_in: Optional[SegmentPlan] = None
@@ -113,6 +113,7 @@ class Structure:
 
     def set_csr(self, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid):
         self.in_ptr, self.in_src, self.in_eid = in_ptr, in_src, in_eid
+        self.in_dst = self.dst[in_eid.long()].to(torch.int32).contiguous()
         self.out_ptr, self.out_dst, self.out_eid = out_ptr, out_dst, out_eid
         # position of every original edge in CSC order, then looked up per CSR slot
         inv = torch.empty(self.num_edges, dtype=torch.int32, device=in_eid.device)
@@ -141,6 +142,7 @@ class Structure:
             s.in_ptr, s.in_src, s.in_eid = (t.to(device) for t in (self.in_ptr, self.in_src, self.in_eid))
             s.out_ptr, s.out_dst, s.out_eid = (t.to(device) for t in (self.out_ptr, self.out_dst, self.out_eid))
             s.out_pos = self.out_pos.to(device)
+            s.in_dst = self.in_dst.to(device)
             s.plan_in, s.plan_out = self.plan_in.to(device), self.plan_out.to(device)
         return s
 

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from ..graph import Graph
 from ..utils.utils import create_norm
-from .gat import GAT
+from .gat import GAT, linear_nobias
 from .loss_func import sce_loss, sce_loss_masked
 
 
@@ -131,7 +131,7 @@ class GMAEModel(nn.Module):
         use_g = pre_use_g
         enc_rep, all_hidden = self.encoder(use_g, pre_use_x, return_hidden=True)
         enc_rep = torch.cat(all_hidden, dim=1)
-        rep = self.encoder_to_decoder(enc_rep)
+        rep = linear_nobias(enc_rep, self.encoder_to_decoder.weight)   # autoencoder.py:237
         recon = self.decoder(pre_use_g, rep)
         # autoencoder.py:242-245: gather of the masked rows fused into the loss kernel
         x_target = g.ndata["attr"]

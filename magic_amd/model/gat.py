@@ -95,11 +95,9 @@ class _GATLayerFn(torch.autograd.Function):
             d_y[:, C + 2 * H:] = d_pre
         d_h = d_w = d_edge = None
         if ctx.needs_input_grad[0]:
-            d_h = d_y @ w_aug
-            if cfg["res_identity"]:
-                d_h = d_h + d_pre
+            d_h = _lib.proj_bwd_input(d_y, w_aug, d_pre if cfg["res_identity"] else None)
         if ctx.needs_input_grad[1]:
-            d_w = d_y.t() @ h
+            d_w = _lib.proj_bwd_weight(d_y, h)
         if ctx.needs_input_grad[2]:
             if etype is not None:
                 d_edge = d_table
@@ -107,6 +105,28 @@ class _GATLayerFn(torch.autograd.Function):
                 d_edge = torch.empty(struct.num_edges, H, dtype=torch.float32, device=h.device)
                 d_edge[struct.in_eid.long()] = rec[:, H:]
         return d_h, d_w, d_edge, d_bias, d_prelu, None, None
+
+
+class _LinearNoBiasFn(torch.autograd.Function):
+    """y = x W^T on the fp32 MFMA kernels (forward, input and weight gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        y, _, _ = _lib.proj_fwd(x, w, w.shape[0], 0, 0)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = _lib.proj_bwd_input(dy, w) if ctx.needs_input_grad[0] else None
+        dw = _lib.proj_bwd_weight(dy, x) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def linear_nobias(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """``torch.nn.functional.linear(x, w)`` for GPU tensors with up to 320 output features."""
+    return _LinearNoBiasFn.apply(x, w)
 
 
 class GATConv(nn.Module):
