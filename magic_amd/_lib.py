@@ -110,6 +110,9 @@ _ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
 def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
     """Grow-only scratch buffer per (device, slot); kernels on one stream run in order, so
     consecutive calls can share it."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise MagicHipError(f"operands must live on the GPU (got {device}); there is no CPU fallback")
     key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:

@@ -133,8 +133,9 @@ def exchange_and_merge(d: torch.Tensor, i: torch.Tensor, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return d, i
-    pd = torch.empty((world,) + tuple(d.shape), dtype=d.dtype, device=d.device)
-    pi = torch.empty((world,) + tuple(i.shape), dtype=i.dtype, device=i.device)
+    q, k = d.shape
+    pd = torch.empty((world * q, k), dtype=d.dtype, device=d.device)
+    pi = torch.empty((world * q, k), dtype=i.dtype, device=i.device)
     dist.all_gather_into_tensor(pd, d.contiguous(), group=group)
     dist.all_gather_into_tensor(pi, i.contiguous(), group=group)
-    return merge_topk(pd, pi)
+    return merge_topk(pd.view(world, q, k), pi.view(world, q, k))

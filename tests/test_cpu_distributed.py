@@ -1,0 +1,116 @@
+"""CPU suite, part 2: the multi-rank paths with world_size 2 over gloo.
+
+The collectives and the host logic around them (flat gradient buffer, shard bounds, list
+exchange and merge) are device independent; on the GPU box the same code runs over RCCL.
+The local top-k lists come from the numpy oracle here (the HIP search needs a GPU)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import knn_oracle
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _dp_worker(rank, world, port, out):
+    from magic_amd.parallel import FlatGradAllReduce, broadcast_parameters
+    from oracle import gat_oracle as O
+    from tests.util import small_graph, to_ograph
+    _init(rank, world, port)
+    torch.manual_seed(100 + rank)          # different initial weights on purpose
+    model = O.build_model(5, 17, 64, 3).eval()
+    broadcast_parameters(model)            # ... made identical here
+    flat = FlatGradAllReduce(model.parameters())
+    n = 150
+    src, dst, nt, et = small_graph(n, 600, 5, 17, seed=50 + rank)
+    g = to_ograph(src, dst, n, nt, et, 5, 17)
+    gen = torch.Generator().manual_seed(rank)
+    perm = torch.randperm(n, generator=gen)
+    neg = O.uniform_negative_pairs(g, n, seed=rank)
+    loss = model.compute_loss(g, perm=perm, pos_idx=torch.arange(n), neg_pairs=neg)
+    flat.zero()
+    loss.backward()
+    flat.check_views()
+    local = flat.flat.clone()
+    flat.allreduce()
+    torch.save({"local": local, "avg": flat.flat.clone(),
+                "w0": torch.cat([p.detach().reshape(-1) for p in model.parameters()])}, f"{out}/dp{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "dp0.pt")
+    r1 = torch.load(tmp_path / "dp1.pt")
+    assert torch.equal(r0["w0"], r1["w0"])                       # broadcast made replicas identical
+    assert not torch.equal(r0["local"], r1["local"])             # different graphs, different grads
+    want = (r0["local"] + r1["local"]) / 2
+    assert torch.equal(r0["avg"], r1["avg"])                     # every rank holds the same average
+    assert torch.allclose(r0["avg"], want, rtol=1e-6, atol=1e-30)
+
+
+def _knn_worker(rank, world, port, out):
+    from magic_amd.knn import ShardedNearestNeighbors, exchange_and_merge
+    _init(rank, world, port)
+    rng = np.random.default_rng(7)
+    base = rng.standard_normal((301, 64)).astype(np.float32)
+    train = np.concatenate([base, base[:50]])                    # duplicates straddle the shards
+    query = rng.standard_normal((40, 64)).astype(np.float32)
+    k = 6
+    lo, hi = ShardedNearestNeighbors.shard_bounds(train.shape[0], world, rank)
+    d, i = knn_oracle.exact_topk(train[lo:hi], query, k)
+    d_t, i_t = torch.from_numpy(d), torch.from_numpy(i + lo)
+    md, mi = exchange_and_merge(d_t, i_t)
+    np.savez(f"{out}/knn{rank}.npz", d=md.numpy(), i=mi.numpy(), lo=lo, hi=hi)
+    dist.destroy_process_group()
+
+
+def test_sharded_knn_merge_equals_single_search_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_knn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(7)
+    base = rng.standard_normal((301, 64)).astype(np.float32)
+    train = np.concatenate([base, base[:50]])
+    query = rng.standard_normal((40, 64)).astype(np.float32)
+    wd, wi = knn_oracle.exact_topk(train, query, 6)
+    r0, r1 = np.load(tmp_path / "knn0.npz"), np.load(tmp_path / "knn1.npz")
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 176, 176, 351)
+    for r in (r0, r1):
+        assert np.array_equal(r["i"], wi)            # ties resolved by index, as in one search
+        assert np.array_equal(r["d"], wd)
+
+
+def test_shard_bounds_cover_everything():
+    from magic_amd.knn import ShardedNearestNeighbors as S
+    from magic_amd.parallel import shard_indices
+    for n in (0, 1, 7, 8, 2604530):
+        for world in (1, 2, 4, 8):
+            b = [S.shard_bounds(n, world, r) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[r][1] == b[r + 1][0] for r in range(world - 1))
+    assert sorted(sum((shard_indices(10, 4, r) for r in range(4)), [])) == list(range(10))
+
+
+def test_merge_topk_host_order_rule():
+    from magic_amd.knn import merge_topk
+    d = torch.tensor([[[0.0, 1.0, 2.0]], [[0.0, 1.0, float("inf")]]], dtype=torch.float64)   # [P=2,Q=1,k=3]
+    i = torch.tensor([[[5, 1, 9]], [[2, 7, -1]]])
+    md, mi = merge_topk(d, i)
+    assert md.tolist() == [[0.0, 0.0, 1.0]] and mi.tolist() == [[2, 5, 1]]

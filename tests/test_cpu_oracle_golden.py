@@ -1,0 +1,315 @@
+"""CPU suite, part 1: the oracle against the golden vectors captured from the reference
+(tests/golden/make_golden.py), plus host logic that needs no GPU."""
+import json
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import csr_oracle, knn_oracle
+from oracle import gat_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+# ----------------------------------------------------------------------------- SCE
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_sce_oracle_matches_reference(tag):
+    z = load(f"sce_{tag}.npz")
+    x = torch.from_numpy(z["x"]).requires_grad_(True)
+    loss = O.sce_loss(x, torch.from_numpy(z["y"]), alpha=int(z["alpha"]))
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) < 1e-7
+    assert np.abs(x.grad.numpy() - z["grad_x"]).max() < 1e-7
+
+
+# ----------------------------------------------------------------------------- KNN
+@pytest.mark.parametrize("tag", ["d64k10", "d256k8", "d2048k2"])
+def test_knn_oracle_matches_sklearn_search(tag):
+    z = load(f"knn_raw_{tag}.npz")
+    assert str(z["algorithm"]) == "brute"       # d >= 16: the reference's search is brute force
+    tr, q = z["train"].astype(np.float32), z["query"].astype(np.float32)
+    d, i = knn_oracle.exact_topk(tr, q, int(z["k"]))
+    assert np.array_equal(i, z["idx"])          # tie-free data: identical neighbour indices
+    # sklearn expands |x|^2-2xy+|y|^2 (float64 GEMM on float32 chunks): its distances carry
+    # float32-level relative error, ~1e-7 * dist, plus ~1e-7 absolute near zero
+    assert (np.abs(d - z["dist"]) < 2e-6 + 2e-7 * z["dist"]).all()
+
+
+def test_knn_oracle_on_duplicates_matches_distances():
+    z = load("knn_raw_dups.npz")
+    d, i = knn_oracle.exact_topk(z["train"], z["query"], int(z["k"]))
+    # exact duplicates tie: sklearn returns tied neighbours in heap order, so only the
+    # distance lists (and the index sets up to ties) are comparable
+    assert np.abs(d - z["dist"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("ds,k", [("trace", 10), ("cadets", 200)])
+def test_entity_level_scores_match_reference(ds, k):
+    z = load("knn_entity.npz")
+    random.seed(1234)
+    mean_distance, dists, score = knn_oracle.entity_scores(z[f"{ds}_x_train"], z[f"{ds}_x_test"], k)
+    assert abs(mean_distance - float(z[f"{ds}_mean_distance"])) < 1e-6
+    assert np.abs(dists - z[f"{ds}_dists"]).max() < 2e-6
+    from sklearn.metrics import roc_auc_score
+    assert abs(roc_auc_score(z[f"{ds}_y_test"], score) - float(z[f"{ds}_auc"])) < 1e-9
+
+
+@pytest.mark.parametrize("ds,train_count", [("streamspot", 400), ("wget", 100)])
+def test_batch_level_scores_match_reference(ds, train_count):
+    from sklearn.metrics import roc_auc_score
+    z = load("knn_batch.npz")
+    x, y = z[f"{ds}_emb"].astype(np.float32), z[f"{ds}_labels"]
+    k = min(int(train_count * 0.02), 10)
+    benign, attack = np.where(y == 0)[0], np.where(y == 1)[0]
+    aucs = []
+    for s in range(3):     # model/eval.py:130-162
+        random.seed(s)
+        np.random.seed(s)
+        torch.manual_seed(s)
+        np.random.shuffle(benign)
+        np.random.shuffle(attack)
+        x_train = x[benign[:train_count]]
+        x_test = np.concatenate([x[benign[train_count:]], x[attack]], axis=0)
+        y_test = np.concatenate([y[benign[train_count:]], y[attack]], axis=0)
+        _, score = knn_oracle.batch_scores(x_train, x_test, k)
+        aucs.append(roc_auc_score(y_test, score))
+    assert abs(np.mean(aucs) - float(z[f"{ds}_auc_rep3"])) < 1e-9
+    assert abs(np.std(aucs) - float(z[f"{ds}_std_rep3"])) < 1e-9
+
+
+# ----------------------------------------------------------------------------- pooling / factories
+def test_pooling_matches_reference():
+    from magic_amd.graph import Graph
+    from magic_amd.utils.poolers import Pooling
+    z = load("pool.npz")
+    g = Graph(torch.zeros(1, dtype=torch.long), torch.zeros(1, dtype=torch.long), 500)
+    g.ndata["type"] = torch.from_numpy(z["type"])
+    feat = torch.from_numpy(z["feat"])
+    assert np.allclose(Pooling("mean")(g, feat).numpy(), z["mean"], atol=1e-6)
+    assert np.allclose(Pooling("sum")(g, feat).numpy(), z["sum"], atol=1e-5)
+    assert np.allclose(Pooling("mean")(g, feat, n_types=8).numpy(), z["mean_typed"], atol=1e-6)
+    assert np.allclose(Pooling("sum")(g, feat, n_types=8).numpy(), z["sum_typed"], atol=1e-5)
+
+
+def test_create_norm_and_activation_follow_reference():
+    from magic_amd.utils.utils import create_activation, create_norm
+    assert create_norm("BatchNorm") is None              # the model's spelling never matches
+    assert create_norm("batchnorm") is torch.nn.BatchNorm1d
+    assert create_norm("layernorm") is torch.nn.LayerNorm
+    assert isinstance(create_activation("prelu"), torch.nn.PReLU)
+    assert isinstance(create_activation(None), torch.nn.Identity)
+    with pytest.raises(NotImplementedError):
+        create_activation("swish")
+    assert O.create_norm("BatchNorm") is None
+
+
+# ----------------------------------------------------------------------------- checkpoints
+DIMS = {"theia": (5, 17), "trace": (11, 23), "cadets": (5, 13)}
+
+
+def _dims(manifest):
+    return manifest["enc_mask_token"][1], manifest["encoder.gats.0.edge_fc.weight"][1]
+
+
+@pytest.mark.parametrize("ds", ["theia", "trace", "cadets", "fivedirections"])
+def test_state_dict_layout_equals_reference_checkpoints(ds):
+    from magic_amd.model.autoencoder import GMAEModel
+    man = json.load(open(os.path.join(G, "checkpoint_manifest.json")))[ds]
+    n_dim, e_dim = _dims(man)
+    mine = GMAEModel(n_dim, e_dim, 64, 3, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3)
+    ref = O.build_model(n_dim, e_dim, 64, 3)
+    for model in (mine, ref):
+        sd = model.state_dict()
+        assert list(sd.keys()) == list(man.keys())
+        assert {k: list(v.shape) for k, v in sd.items()} == man
+    assert len(man) == 38
+
+
+def test_reference_checkpoint_loads_into_both_models():
+    from magic_amd.model.autoencoder import GMAEModel
+    z = load("checkpoint_theia.npz")
+    sd = {k: torch.from_numpy(z[k]) for k in z.files}
+    mine = GMAEModel(5, 17, 64, 3, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3)
+    ref = O.build_model(5, 17, 64, 3)
+    mine.load_state_dict(sd, strict=True)
+    ref.load_state_dict(sd, strict=True)
+    assert sum(v.numel() for v in sd.values()) == 59122
+
+
+def test_same_seed_gives_same_initial_weights():
+    from magic_amd.model.autoencoder import GMAEModel
+    torch.manual_seed(0)
+    ref = O.build_model(8, 20, 256, 4)
+    torch.manual_seed(0)
+    mine = GMAEModel(8, 20, 256, 4, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3)
+    for (k1, v1), (k2, v2) in zip(ref.state_dict().items(), mine.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    assert sum(p.numel() for p in mine.parameters()) == 1215181
+
+
+def test_mask_indices_follow_cpu_generator():
+    from magic_amd.model.autoencoder import GMAEModel
+    gold = json.load(open(os.path.join(G, "randperm.json")))
+    m = GMAEModel(5, 17, 64, 3, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3)
+    for key, want in gold.items():
+        seed, n = (int(t) for t in key.split("_"))
+        torch.manual_seed(seed)
+        p = m._randperm(n, torch.device("cpu"))
+        assert p[:16].tolist() == want["head"] and p[-4:].tolist() == want["tail"]
+        assert int(p[: n // 2].sum()) == want["sum_head_half"]
+    torch.manual_seed(0)
+    assert torch.randperm(10).tolist() == gold["0_10"]["head"][:10]
+
+
+# ----------------------------------------------------------------------------- CSR / plan / batch
+def _rand_graph(n, e, seed):
+    from magic_amd import synth
+    rng = np.random.default_rng(seed)
+    return synth.power_law_edges(n, e, rng)
+
+
+def test_csr_oracle_matches_scipy():
+    import scipy.sparse as sp
+    n = 400
+    src, dst = _rand_graph(n, 3000, 1)
+    # scipy sorts the minor index inside every row / column; an edge list ordered by (src, dst)
+    # makes "ascending original edge id" the same order in both directions
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid = csr_oracle.build(src, dst, n)
+    data = np.arange(src.size) + 1
+    csc = sp.coo_matrix((data, (src, dst)), shape=(n, n)).tocsc()     # column = destination
+    assert np.array_equal(csc.indptr, in_ptr) and np.array_equal(csc.indices, in_src)
+    assert np.array_equal(csc.data - 1, in_eid)
+    csr = sp.coo_matrix((data, (src, dst)), shape=(n, n)).tocsr()     # row = source
+    assert np.array_equal(csr.indptr, out_ptr) and np.array_equal(csr.indices, out_dst)
+    assert np.array_equal(csr.data - 1, out_eid)
+
+
+def test_segment_plan_matches_oracle():
+    from magic_amd.graph import CHUNK, LIGHT_MAX, build_segment_plan
+    n = 300
+    src, dst = _rand_graph(n, 6000, 2)
+    dst[:700] = 7          # one very long segment
+    ptr = csr_oracle.csr_by_key(dst, src, n)[0]
+    plan = build_segment_plan(torch.from_numpy(ptr))
+    hv, cp, cn, cb, ce = csr_oracle.segment_plan(ptr, LIGHT_MAX, CHUNK)
+    assert np.array_equal(plan.heavy_node.numpy(), hv) and np.array_equal(plan.heavy_cptr.numpy(), cp)
+    assert np.array_equal(plan.chunk_node.numpy(), cn)
+    assert np.array_equal(plan.chunk_beg.numpy(), cb) and np.array_equal(plan.chunk_end.numpy(), ce)
+    assert hv.size >= 1 and (ce - cb).max() == CHUNK
+    empty = build_segment_plan(torch.zeros(5, dtype=torch.int32))
+    assert empty.n_heavy == 0 and empty.n_chunks == 0
+
+
+def test_batch_concatenates_csr_bit_exact():
+    from magic_amd.graph import Graph, batch
+    graphs, srcs, dsts, off = [], [], [], 0
+    for i in range(4):
+        n = 100 + 13 * i
+        src, dst = _rand_graph(n, 500 + 50 * i, 10 + i)
+        g = Graph(torch.from_numpy(src), torch.from_numpy(dst), n)
+        g.structure.set_csr(*(torch.from_numpy(a) for a in csr_oracle.build(src, dst, n)))
+        g.ndata["type"] = torch.full((n,), i)
+        graphs.append(g)
+        srcs.append(src + off)
+        dsts.append(dst + off)
+        off += n
+    bg = batch(graphs)
+    want = csr_oracle.build(np.concatenate(srcs), np.concatenate(dsts), off)
+    s = bg.structure
+    for w, got in zip(want, (s.in_ptr, s.in_src, s.in_eid, s.out_ptr, s.out_dst, s.out_eid)):
+        assert got.dtype == torch.int32 and np.array_equal(w, got.numpy())
+    assert bg.num_nodes() == off and bg.batch_num_nodes() == [g.num_nodes() for g in graphs]
+    assert torch.equal(bg.ndata["type"], torch.cat([g.ndata["type"] for g in graphs]))
+
+
+def test_graph_clone_shares_feature_storage_like_dgl():
+    from magic_amd.graph import Graph
+    g = Graph(torch.tensor([0, 1]), torch.tensor([1, 2]), 3)
+    g.ndata["attr"] = torch.eye(3)
+    c = g.clone()
+    c.ndata["attr"][1] = 7.0              # in-place write is visible through the original
+    assert float(g.ndata["attr"][1, 0]) == 7.0
+    c.ndata["new"] = torch.zeros(3)       # but the dictionaries are separate
+    assert "new" not in g.ndata
+    with g.local_scope():
+        g.ndata["tmp"] = torch.ones(3)
+    assert "tmp" not in g.ndata
+
+
+def test_oracle_alias_switch_changes_only_the_sce_target():
+    from tests.util import small_graph, to_ograph
+    n = 200
+    src, dst, nt, et = small_graph(n, 800, 5, 17, 3)
+    torch.manual_seed(0)
+    m = O.build_model(5, 17, 64, 3).eval()
+    with torch.no_grad():
+        m.enc_mask_token.fill_(0.25)
+    perm = torch.randperm(n)
+    pos = torch.arange(n)
+    neg = (torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long))
+    outs = {}
+    for alias in (True, False):
+        m.alias_clone = alias
+        g = to_ograph(src, dst, n, nt, et, 5, 17)
+        _, parts = m.compute_loss(g, perm=perm, pos_idx=pos, neg_pairs=neg, return_parts=True)
+        outs[alias] = parts
+        touched = not torch.equal(g.ndata["attr"], torch.nn.functional.one_hot(torch.from_numpy(nt), 5).float())
+        assert touched == alias
+    assert torch.equal(outs[True]["recon"], outs[False]["recon"])
+    assert float(outs[True]["sce"]) != float(outs[False]["sce"])
+    assert float(outs[True]["bce"]) == float(outs[False]["bce"])
+
+
+# ----------------------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    from magic_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "magic_hip.h")).read()
+    declared = set(re.findall(r"\b(magic_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes found"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.magic_abi_version() >= 1
+    assert lib.magic_status_string(0) == b"ok"
+    assert lib.magic_status_string(-3) == b"workspace missing or too small"
+    # size queries are host-only arithmetic and must work without a GPU
+    assert lib.magic_gat_fwd_workspace_bytes(1000, 10, 4, 16) > 1000 * 4 * 4
+    assert lib.magic_knn_workspace_bytes(1000, 10, 64, 5) >= 8000
+
+
+def test_product_path_has_no_cpu_fallback():
+    from magic_amd import _lib
+    from magic_amd.graph import Graph
+    from magic_amd.model.gat import GATConv
+    from magic_amd.model.loss_func import sce_loss
+    g = Graph(torch.tensor([0, 1]), torch.tensor([1, 2]), 3)
+    g.edata["attr"] = torch.eye(2)
+    conv = GATConv(4, 2, 4, 4)
+    with pytest.raises(_lib.MagicHipError):
+        conv(g, torch.randn(3, 4))
+    with pytest.raises(_lib.MagicHipError):
+        sce_loss(torch.randn(3, 4), torch.randn(3, 4))
+    with pytest.raises(RuntimeError):
+        g.structure.ensure_csr()
+    with pytest.raises(_lib.MagicHipError):
+        _lib.knn_topk(torch.randn(8, 64), torch.randn(2, 64), 2)
+
+
+def test_product_does_not_import_the_oracle():
+    root = os.path.join(os.path.dirname(__file__), "..", "magic_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
