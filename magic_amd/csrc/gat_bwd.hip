@@ -74,6 +74,41 @@ __global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a) {
         add4(bsum, go);
         const int b = a.pin.ptr[v], e = a.pin.ptr[v + 1];
         if (e - b > a.pin.light_max) continue;
+        if (e - b <= 4) {
+            // short segment (the common case): everything stays in registers, one batch of
+            // clamped loads, the record is written once
+            const int deg = e - b;
+            float det = 0.f;
+            if (deg > 0) {
+                float4 r[4];
+                float ap[4], da[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ii = min(b + j, e - 1);
+                    r[j] = ld4(a.hs + (int64_t)a.in_src[ii] * a.ld_hs + g * 4);
+                    ap[j] = a.attn[(int64_t)ii * H + h];
+                }
+                float delta = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    da[j] = head_sum<LPH>(dot4(r[j], go));
+                    delta = j < deg ? fmaf(fabsf(ap[j]), da[j], delta) : delta;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < deg) {
+                        const float aw = fabsf(ap[j]);
+                        float dl = aw * (da[j] - delta);
+                        if (attn_neg(ap[j])) dl *= a.slope;
+                        a.rec[(int64_t)(b + j) * 2 * H + h] = aw;
+                        a.rec[(int64_t)(b + j) * 2 * H + H + h] = dl;
+                        det += dl;
+                    }
+                }
+            }
+            if ((g % LPH) == 0) a.d_y[(int64_t)v * a.ld_dy + C + H + h] = det;
+            continue;
+        }
         // sweep 1: d_a per edge (parked in the record's d_logit slot) and delta = sum a d_a
         float delta = 0.f;
         int i = b;
@@ -89,12 +124,23 @@ __global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a) {
                 a.rec[(int64_t)(i + j) * 2 * H + H + h] = da;
             }
         }
-        for (; i < e; ++i) {
-            float4 r = ld4(a.hs + (int64_t)a.in_src[i] * a.ld_hs + g * 4);
-            float da = head_sum<LPH>(dot4(r, go));
-            float aw = fabsf(a.attn[(int64_t)i * H + h]);
-            delta = fmaf(aw, da, delta);
-            a.rec[(int64_t)i * 2 * H + H + h] = da;
+        if (i < e) {  // tail of 1..3 edges as one clamped batch
+            float4 r[3];
+            float aw[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ii = min(i + j, e - 1);
+                r[j] = ld4(a.hs + (int64_t)a.in_src[ii] * a.ld_hs + g * 4);
+                aw[j] = fabsf(a.attn[(int64_t)ii * H + h]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float da = head_sum<LPH>(dot4(r[j], go));
+                if (i + j < e) {
+                    delta = fmaf(aw[j], da, delta);
+                    a.rec[(int64_t)(i + j) * 2 * H + H + h] = da;
+                }
+            }
         }
         // sweep 2: d_logit (every lane re-reads the value it stored itself)
         float det = 0.f;
@@ -276,11 +322,24 @@ __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
                 deh += dl[t];
             }
         }
-        for (; j < e; ++j) {
-            int pos = a.out_pos[j];
-            float4 r = ld4(a.d_pre + (int64_t)a.out_dst[j] * a.ld_dpre + g * 4);
-            fma4(acc, a.rec[(int64_t)pos * 2 * H + h], r);
-            deh += a.rec[(int64_t)pos * 2 * H + H + h];
+        if (j < e) {  // tail of 1..3 edges as one clamped batch
+            float4 r[3];
+            float w[3], dl[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int jj = min(j + t, e - 1);
+                const int pos = a.out_pos[jj];
+                r[t] = ld4(a.d_pre + (int64_t)a.out_dst[jj] * a.ld_dpre + g * 4);
+                w[t] = a.rec[(int64_t)pos * 2 * H + h];
+                dl[t] = a.rec[(int64_t)pos * 2 * H + H + h];
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (j + t < e) {
+                    fma4(acc, w[t], r[t]);
+                    deh += dl[t];
+                }
+            }
         }
         st4(a.d_y + (int64_t)u * a.ld_dy + g * 4, acc);
         if ((g % LPH) == 0) a.d_y[(int64_t)u * a.ld_dy + C + h] = deh;

@@ -86,37 +86,80 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
     const bool writer = q == 0;
     for (int v = blockIdx.x * NPB + slot; v < a.N; v += gridDim.x * NPB) {
         const int b = a.plan.ptr[v], e = a.plan.ptr[v + 1];
-        if (e - b > a.plan.light_max) continue;
-        float m = -INFINITY;
-        for (int i = b + q; i < e; i += LPH) m = fmaxf(m, leaky(a.x[(int64_t)i * H + h], a.slope));
-        m = head_max<LPH>(m);
-        float s = 0.f;
-        for (int i = b + q; i < e; i += LPH) s += __expf(leaky(a.x[(int64_t)i * H + h], a.slope) - m);
-        s = head_sum<LPH>(s);
-        const float inv = 1.f / s;
+        const int deg = e - b;
+        if (deg > a.plan.light_max) continue;
         float4 acc = f4zero();
-        int i = b;
-        for (; i + 4 <= e; i += 4) {
+        if (deg > 0 && deg <= 4) {
+            // short segment (the common case): one batch of clamped loads, one dependent chain
+            float x[4], l[4], p[4];
             float4 r[4];
-            float w[4], x[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)a.src[i + j] * a.ld_hs + g * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = a.x[(int64_t)(i + j) * H + h];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                w[j] = __expf(leaky(x[j], a.slope) - m) * inv;
-                if (writer) a.attn[(int64_t)(i + j) * H + h] = pack_attn(w[j], x[j]);
+                const int ii = min(b + j, e - 1);
+                r[j] = ld4(a.hs + (int64_t)a.src[ii] * a.ld_hs + g * 4);
+                x[j] = a.x[(int64_t)ii * H + h];
+                l[j] = leaky(x[j], a.slope);
             }
+            float m = l[0];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fma4(acc, w[j], r[j]);
-        }
-        for (; i < e; ++i) {
-            float4 r = ld4(a.hs + (int64_t)a.src[i] * a.ld_hs + g * 4);
-            float x = a.x[(int64_t)i * H + h];
-            float w = __expf(leaky(x, a.slope) - m) * inv;
-            if (writer) a.attn[(int64_t)i * H + h] = pack_attn(w, x);
-            fma4(acc, w, r);
+            for (int j = 1; j < 4; ++j) m = j < deg ? fmaxf(m, l[j]) : m;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p[j] = j < deg ? __expf(l[j] - m) : 0.f;
+                s += p[j];
+            }
+            const float inv = 1.f / s;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < deg) {
+                    const float w = p[j] * inv;
+                    if (writer) a.attn[(int64_t)(b + j) * H + h] = pack_attn(w, x[j]);
+                    fma4(acc, w, r[j]);
+                }
+            }
+        } else if (deg > 4) {
+            float m = -INFINITY;
+            for (int i = b + q; i < e; i += LPH) m = fmaxf(m, leaky(a.x[(int64_t)i * H + h], a.slope));
+            m = head_max<LPH>(m);
+            float s = 0.f;
+            for (int i = b + q; i < e; i += LPH) s += __expf(leaky(a.x[(int64_t)i * H + h], a.slope) - m);
+            s = head_sum<LPH>(s);
+            const float inv = 1.f / s;
+            int i = b;
+            for (; i + 4 <= e; i += 4) {
+                float4 r[4];
+                float w[4], x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)a.src[i + j] * a.ld_hs + g * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = a.x[(int64_t)(i + j) * H + h];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w[j] = __expf(leaky(x[j], a.slope) - m) * inv;
+                    if (writer) a.attn[(int64_t)(i + j) * H + h] = pack_attn(w[j], x[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fma4(acc, w[j], r[j]);
+            }
+            if (i < e) {  // tail of 1..3 edges: clamped batch so that the gathers overlap
+                float4 r[3];
+                float x[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int ii = min(i + j, e - 1);
+                    r[j] = ld4(a.hs + (int64_t)a.src[ii] * a.ld_hs + g * 4);
+                    x[j] = a.x[(int64_t)ii * H + h];
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (i + j < e) {
+                        const float w = __expf(leaky(x[j], a.slope) - m) * inv;
+                        if (writer) a.attn[(int64_t)(i + j) * H + h] = pack_attn(w, x[j]);
+                        fma4(acc, w, r[j]);
+                    }
+                }
+            }
         }
         epilogue<H, LPH>(a, v, g, acc);
     }

@@ -140,6 +140,192 @@ __global__ __launch_bounds__(256) void k_proj(ProjArgs a) {
     }
 }
 
+// Streaming variant for K <= 32*KCH small enough that the whole weight block fits in LDS:
+// W is staged once per block; afterwards the four waves are independent -- each walks 32-row
+// tiles, copies its tile through a private LDS strip with coalesced 16-byte loads (the next
+// tile's loads are issued before the current tile's MFMAs), and never meets a block barrier.
+template <int NCT, int KCH>
+__global__ __launch_bounds__(256) void k_proj_stream(ProjArgs a) {
+    constexpr int KP = KCH * 32;
+    constexpr int LDW = KP + 4;          // 16-B aligned rows, 4-bank skew between rows
+    constexpr int NV = KP / 8;           // float4 per lane per tile
+    extern __shared__ __align__(16) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hf = lane >> 5, lr = lane & 31;
+    float *ws = sm;
+    float *xs = sm + NCT * 32 * LDW + wave * 32 * LDW;
+    const bool wvec = (a.F % 4 == 0) && a.w_cs == 1 && (a.w_rs % 4 == 0) && ((uintptr_t)a.w % 16 == 0);
+    for (int idx = tid; idx < NCT * 32 * (KP / 4); idx += 256) {
+        const int r = idx / (KP / 4), c4 = (idx % (KP / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.col0 + r < a.M) {
+            const float *p = a.w + (int64_t)(a.col0 + r) * a.w_rs + (int64_t)c4 * a.w_cs;
+            if (wvec && c4 + 3 < a.F) {
+                v = *reinterpret_cast<const float4 *>(p);
+            } else {
+                if (c4 + 0 < a.F) v.x = p[0];
+                if (c4 + 1 < a.F) v.y = p[a.w_cs];
+                if (c4 + 2 < a.F) v.z = p[2 * a.w_cs];
+                if (c4 + 3 < a.F) v.w = p[3 * a.w_cs];
+            }
+        }
+        *reinterpret_cast<float4 *>(ws + r * LDW + c4) = v;
+    }
+    __syncthreads();
+    const bool vec = (a.F % 4 == 0) && (a.ld_x % 4 == 0) && ((uintptr_t)a.x % 16 == 0);
+    const int64_t n_tiles = (a.n + 31) / 32;
+    const int64_t t_stride = (int64_t)gridDim.x * 4;
+    float4 v[NV];
+    auto load_tile = [&](int64_t t) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = lane + 64 * i;
+            const int r = idx / (KP / 4), c4 = (idx % (KP / 4)) * 4;
+            const int64_t row = t * 32 + r;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < a.n && c4 < a.F) {
+                const float *p = a.x + row * a.ld_x + c4;
+                if (vec && c4 + 3 < a.F) {
+                    q = *reinterpret_cast<const float4 *>(p);
+                } else {
+                    q.x = p[0];
+                    if (c4 + 1 < a.F) q.y = p[1];
+                    if (c4 + 2 < a.F) q.z = p[2];
+                    if (c4 + 3 < a.F) q.w = p[3];
+                }
+            }
+            v[i] = q;
+        }
+    };
+    int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    if (t < n_tiles) load_tile(t);
+    for (; t < n_tiles; t += t_stride) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = lane + 64 * i;
+            const int r = idx / (KP / 4), c4 = (idx % (KP / 4)) * 4;
+            *reinterpret_cast<float4 *>(xs + r * LDW + c4) = v[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (t + t_stride < n_tiles) load_tile(t + t_stride);   // in flight behind the MFMAs below
+        float16_t acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < KCH; ++ch) {
+            float af[16];
+            {
+                const float *p = xs + lr * LDW + ch * 32 + hf * 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 q = *reinterpret_cast<const float4 *>(p + 4 * j);
+                    af[4 * j] = q.x;
+                    af[4 * j + 1] = q.y;
+                    af[4 * j + 2] = q.z;
+                    af[4 * j + 3] = q.w;
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                float bf[16];
+                const float *p = ws + (ct * 32 + lr) * LDW + ch * 32 + hf * 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 q = *reinterpret_cast<const float4 *>(p + 4 * j);
+                    bf[4 * j] = q.x;
+                    bf[4 * j + 1] = q.y;
+                    bf[4 * j + 2] = q.z;
+                    bf[4 * j + 3] = q.w;
+                }
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc[ct], 0, 0, 0);
+            }
+        }
+        const bool full_rows = t * 32 + 32 <= a.n;   // wave-uniform
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int c_lo = a.col0 + ct * 32;
+            const int col = c_lo + lr;
+            // whole column tile inside one destination and all 32 rows valid: plain strided stores
+            float *dst = nullptr;
+            int64_t ld = 0;
+            if (full_rows) {
+                if (c_lo + 32 <= a.C) {
+                    dst = a.hs + col;
+                    ld = a.ld_hs;
+                } else if (c_lo >= a.C + a.NS && c_lo + 32 <= a.M) {
+                    dst = a.res + (col - a.C - a.NS);
+                    ld = a.ld_res;
+                }
+            }
+            if (dst) {
+                float *p = dst + (t * 32 + 4 * hf) * ld;
+                if (a.add && c_lo + 32 <= a.C) {
+                    const float *q = a.add + (t * 32 + 4 * hf) * a.ld_add + col;
+                    float ad[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ad[r] = q[((r & 3) + 8 * (r >> 2)) * a.ld_add];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * ld] = acc[ct][r] + ad[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * ld] = acc[ct][r];
+                }
+                continue;
+            }
+            const int c_hi = c_lo + 32 < a.M ? c_lo + 32 : a.M;
+            if (full_rows && c_lo >= a.C && c_hi <= a.C + a.NS) {  // tile holds score columns only
+                if (col < c_hi) {
+                    float *p = a.score + (t * 32 + 4 * hf) * a.NS + (col - a.C);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * a.NS] = acc[ct][r];
+                }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                if (row >= a.n) continue;
+                float val = acc[ct][r];
+                if (col < a.C) {
+                    if (a.add) val += a.add[row * a.ld_add + col];
+                    a.hs[row * a.ld_hs + col] = val;
+                } else if (col < a.C + a.NS) {
+                    a.score[row * a.NS + (col - a.C)] = val;
+                } else if (col < a.M) {
+                    a.res[row * a.ld_res + (col - a.C - a.NS)] = val;
+                }
+            }
+        }
+    }
+}
+
+template <int NCT, int KCH> int launch_stream(const ProjArgs &a, hipStream_t stream) {
+    constexpr int LDW = KCH * 32 + 4;
+    size_t sh = (size_t)(NCT * 32 + 4 * 32) * LDW * sizeof(float);
+    static bool attr_set = false;
+    if (sh > 48 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_proj_stream<NCT, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sh);
+        attr_set = true;
+    }
+    int64_t tiles = (a.n + 31) / 32;
+    int blocks_per_cu = sh <= 40 * 1024 ? 4 : (sh <= 80 * 1024 ? 2 : 1);
+    int64_t want = (tiles + 3) / 4;
+    int64_t cap = 256 * blocks_per_cu;
+    unsigned grid = (unsigned)(want < cap ? want : cap);
+    MAGIC_LAUNCH(a.name, (k_proj_stream<NCT, KCH>), grid, 256, sh, stream, a);
+    return magic::launch_status();
+}
+
+// (column tiles, 32-wide K chunks) pairs with a streaming instantiation
+#define MAGIC_PROJ_STREAM_SHAPES(X) \
+    X(5, 1) X(3, 2) X(2, 6) X(1, 2) X(2, 1) X(6, 2) X(2, 3) X(1, 5) X(1, 1) X(2, 2) X(3, 1) X(4, 1) X(8, 1)
+
 template <int NCT> int launch(const ProjArgs &a, hipStream_t stream) {
     size_t sh = (size_t)(BM + NCT * 32) * LDS_LD * sizeof(float);
     unsigned grid = (unsigned)((a.n + BM - 1) / BM);
@@ -222,6 +408,11 @@ int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim, const f
 
 namespace {
 int dispatch_one(const ProjArgs &a, int nct, hipStream_t stream) {
+    const int kch = (a.F + 31) / 32;
+#define X(n, k) \
+    if (nct == n && kch == k) return launch_stream<n, k>(a, stream);
+    MAGIC_PROJ_STREAM_SHAPES(X)
+#undef X
     switch (nct) {
         case 1: return launch<1>(a, stream);
         case 2: return launch<2>(a, stream);

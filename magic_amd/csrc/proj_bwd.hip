@@ -28,7 +28,7 @@ struct DwArgs {
 
 template <int MT, int FT>
 __global__ __launch_bounds__(256) void k_proj_dw(DwArgs a) {
-    extern __shared__ float lds[];  // 3 waves x MT*FT*16*64 floats
+    extern __shared__ float lds[];  // MT*FT*16*64 floats
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hf = lane >> 5, li = lane & 31;
     const int strip = blockIdx.x;
@@ -73,15 +73,20 @@ __global__ __launch_bounds__(256) void k_proj_dw(DwArgs a) {
     }
     // waves 1..3 park their tiles in LDS; wave 0 adds them in wave order and writes the block partial
     constexpr int TILE = MT * FT * 16 * 64;
-    if (wave > 0) {
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int ft = 0; ft < FT; ++ft)
+                for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) lds[(wave - 1) * TILE + ((mt * FT + ft) * 16 + r) * 64 + lane] = acc[mt][ft][r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = ((mt * FT + ft) * 16 + r) * 64 + lane;
+                        lds[o] = w == 1 ? acc[mt][ft][r] : lds[o] + acc[mt][ft][r];
+                    }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (wave == 0) {
         float *out = a.partial + ((int64_t)strip * gridDim.y + grp) * TILE;
 #pragma unroll
@@ -91,11 +96,7 @@ __global__ __launch_bounds__(256) void k_proj_dw(DwArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int o = ((mt * FT + ft) * 16 + r) * 64 + lane;
-                    float v = acc[mt][ft][r];
-                    v += lds[o];
-                    v += lds[TILE + o];
-                    v += lds[2 * TILE + o];
-                    out[o] = v;
+                    out[o] = acc[mt][ft][r] + lds[o];
                 }
     }
 }
@@ -139,9 +140,8 @@ DwPlan plan_dw(int64_t n, int M, int F) {
     p.mg = (mtiles + p.mt - 1) / p.mt;
     p.fg = (ftiles + p.ft - 1) / p.ft;
     int groups = p.mg * p.fg;
-    int strips = 512 / groups;
+    int strips = 1024 / groups;  // ~4 blocks per CU in flight
     if (strips < 8) strips = 8;
-    if (strips > 256) strips = 256;
     int64_t waves = (int64_t)strips * 4;
     int64_t rpw = (n + waves - 1) / waves;
     rpw = (rpw + 7) / 8 * 8;  // whole unrolled iterations
@@ -155,7 +155,7 @@ DwPlan plan_dw(int64_t n, int M, int F) {
 
 template <int MT, int FT> int run_dw(DwArgs &a, const DwPlan &p, hipStream_t stream) {
     constexpr int TILE = MT * FT * 16 * 64;
-    size_t sh = (size_t)3 * TILE * sizeof(float);
+    size_t sh = (size_t)TILE * sizeof(float);
     static bool attr_set = false;
     if (sh > 48 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute((const void *)k_proj_dw<MT, FT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
