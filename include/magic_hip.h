@@ -98,22 +98,46 @@ typedef struct magic_plan {
  * (v_mfma_f32_32x32x2_f32, bit-equal to an fmaf chain over k).
  * ---------------------------------------------------------------------------------- */
 int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_score, int32_t res_c,
-                   const float *x, int64_t ld_x, const float *w /* [C+n_score+res_c, in_dim] */,
+                   const float *x, int64_t ld_x,
+                   const uint8_t *x_mask /* [N,in_dim] dropout keep mask applied to x, or NULL */, float x_scale,
+                   const float *w /* [C+n_score+res_c, in_dim] */,
                    float *hs, int64_t ld_hs, float *score, float *res, int64_t ld_res,
                    void *stream);
 
 /* Backward of magic_proj_fwd (the adjoints torch autograd forms for nn.Linear at
- * model/gat.py:284,:323 and model/autoencoder.py:237):
- *   magic_proj_bwd_input : dX[N,out_dim] = dY[N,k_dim] . W[k_dim,out_dim] (+ add[N,out_dim])
- *   magic_proj_bwd_weight: dW[M,F]       = dY[N,M]^T . X[N,F]   (fixed-order reduction over N)
+ * model/gat.py:284,:323 and model/autoencoder.py:237, and for nn.Dropout at model/gat.py:283
+ * and nn.PReLU at :335 when they are fused in):
+ *   magic_proj_bwd_input : dX[N,out_dim] = epilogue( dY[N,k_dim] . W[k_dim,out_dim] )
+ *   magic_proj_bwd_weight: dW[M,F]       = dY[N,M]^T . (X[N,F] (.) x_mask * x_scale)
+ *                          (fixed-order reduction over N)
+ * The epilogue (all parts optional, applied in this order to every output element):
+ *   v += add[row,col];  v = out_mask[row,col] ? v*out_scale : 0;  v += add2[row,col];
+ *   PReLU adjoint of the layer that produced the projected input: with pre the
+ *   pre-activation (recovered from act_out when *prelu_w > 0, read from act_pre otherwise),
+ *   pre <= 0 ?  (prelu_grad += v*pre, v *= *prelu_w) : nothing;
+ *   col_sum[col] += v  (bias gradient of that layer).
  */
+typedef struct magic_proj_epilogue {
+    const float *add;        int64_t ld_add;
+    const uint8_t *out_mask; float out_scale;      /* [N,out_dim] contiguous */
+    const float *add2;       int64_t ld_add2;
+    const float *act_out;    int64_t ld_act;       /* forward output of the producing layer */
+    const float *act_pre;                          /* [N,out_dim] its pre-activation */
+    const float *prelu_w;                          /* device scalar */
+    float *col_sum;                                /* [out_dim] or NULL */
+    float *prelu_grad;                             /* [1] or NULL */
+} magic_proj_epilogue;
+
+size_t magic_proj_bwd_input_workspace_bytes(int64_t n_rows, int32_t k_dim, int32_t out_dim);
 int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim,
                          const float *dy, int64_t ld_dy, const float *w /* [k_dim,out_dim] */,
-                         const float *add /* optional */, int64_t ld_add,
-                         float *dx, int64_t ld_dx, void *stream);
+                         const magic_proj_epilogue *epilogue /* host struct, may be NULL */,
+                         float *dx, int64_t ld_dx,
+                         void *workspace, size_t workspace_bytes, void *stream);
 size_t magic_proj_bwd_weight_workspace_bytes(int64_t n_rows, int32_t m, int32_t f);
 int magic_proj_bwd_weight(int64_t n_rows, int32_t m, int32_t f,
                           const float *dy, int64_t ld_dy, const float *x, int64_t ld_x,
+                          const uint8_t *x_mask /* [N,f] or NULL */, float x_scale,
                           float *dw /* [m,f] */, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
@@ -139,6 +163,7 @@ int magic_gat_fwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t hea
                   const float *eh, const float *et, int64_t ld_score /* row stride of eh and et */,
                   const float *ee_table, const int32_t *etype_csc, const float *ee_csc,
                   float negative_slope, const float *bias, const float *res, int64_t ld_res,
+                  const uint8_t *res_mask /* [N,H*D] dropout keep mask of res, or NULL */, float res_scale,
                   const float *prelu_w,
                   float *out, int64_t ld_out, float *pre, float *attn,
                   void *workspace, size_t workspace_bytes, void *stream);
@@ -163,7 +188,9 @@ int magic_gat_bwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t hea
                   const magic_plan *out_plan, const int32_t *out_dst, const int32_t *out_pos,
                   const float *hs, int64_t ld_hs, const float *attn,
                   const int32_t *etype_csc, int32_t e_dim,
-                  float negative_slope, const float *pre, const float *prelu_w,
+                  float negative_slope, const float *pre,
+                  const float *act_out, int64_t ld_act /* forward output, used when *prelu_w > 0 */,
+                  const float *prelu_w,
                   const float *d_out, int64_t ld_dout,
                   float *d_pre, int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table,
                   float *edge_rec,

@@ -35,18 +35,20 @@ SYMBOLS = {
     "magic_prof_read": (c_i32, [c_i32, C.c_char_p, C.POINTER(c_i64), C.POINTER(C.c_double)]),
     "magic_csr_build_workspace_bytes": (c_i32, [c_i64, c_i64, C.POINTER(c_sz)]),
     "magic_csr_build": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "magic_proj_fwd": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp,
-                               c_i64, c_vp]),
-    "magic_proj_bwd_input": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "magic_proj_fwd": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_i64,
+                               c_vp, c_vp, c_i64, c_vp]),
+    "magic_proj_bwd_input_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
+    "magic_proj_bwd_input": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "magic_proj_bwd_weight_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
-    "magic_proj_bwd_weight": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "magic_proj_bwd_weight": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_sz,
+                                      c_vp]),
     "magic_gat_fwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "magic_gat_fwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, c_vp,
-                              c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp,
+                              c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp,
                               c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_gat_bwd_workspace_bytes": (c_sz, [c_i32] * 7),
     "magic_gat_bwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, C.POINTER(MagicPlan), c_vp,
-                              c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_i64,
+                              c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64,
                               c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_sce_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "magic_sce_fwd_bwd": (c_i32, [c_i64, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32,
@@ -180,88 +182,133 @@ def make_plan(plan, light_max: int) -> MagicPlan:
 
 
 # ------------------------------------------------------------------------------------- projection
-def proj_fwd(x: torch.Tensor, w: torch.Tensor, out_c: int, n_score: int, res_c: int):
-    """hs [N,out_c], score [N,n_score] | None, res [N,res_c] | None  =  split(x @ w.T)."""
+class ProjEpilogue(C.Structure):
+    _fields_ = [("add", c_vp), ("ld_add", c_i64), ("out_mask", c_vp), ("out_scale", c_f32),
+                ("add2", c_vp), ("ld_add2", c_i64), ("act_out", c_vp), ("ld_act", c_i64),
+                ("act_pre", c_vp), ("prelu_w", c_vp), ("col_sum", c_vp), ("prelu_grad", c_vp)]
+
+
+def _rows(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """2-D operand with unit inner stride (row stride free)."""
+    if t is None:
+        return None
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def proj_fwd(x: torch.Tensor, w: torch.Tensor, out_c: int, n_score: int, res_c: int,
+             x_mask: Optional[torch.Tensor] = None, x_scale: float = 1.0):
+    """hs [N,out_c], score [N,n_score] | None, res [N,res_c] | None  =  split((x * mask * scale) @ w.T)."""
     lib = load()
     assert x.dim() == 2 and w.dim() == 2 and w.shape[1] == x.shape[1] and w.shape[0] == out_c + n_score + res_c
-    if x.stride(1) != 1:
-        x = x.contiguous()
+    x = _rows(x)
     w = w.contiguous()
     N, F = x.shape
     dev = x.device
+    if x_mask is not None:
+        assert x_mask.dtype == torch.uint8 and x_mask.shape == x.shape and x_mask.is_contiguous()
     hs = torch.empty(N, out_c, dtype=torch.float32, device=dev)
     score = torch.empty(N, n_score, dtype=torch.float32, device=dev) if n_score else None
     res = torch.empty(N, res_c, dtype=torch.float32, device=dev) if res_c else None
     _check(lib.magic_proj_fwd(N, F, out_c, n_score, res_c, _dev(x, torch.float32, "x"), x.stride(0),
-                              _dev(w, torch.float32, "w"), _dev(hs), out_c, _dev(score), _dev(res), res_c,
-                              _stream()), "magic_proj_fwd")
+                              _dev(x_mask), float(x_scale), _dev(w, torch.float32, "w"), _dev(hs), out_c,
+                              _dev(score), _dev(res), res_c, _stream()), "magic_proj_fwd")
     return hs, score, res
 
 
-def proj_bwd_input(dy: torch.Tensor, w: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dX = dy @ w (+ add); dy [N,K] (unit inner stride), w [K,F]."""
+def proj_bwd_input(dy: torch.Tensor, w: torch.Tensor, add: Optional[torch.Tensor] = None,
+                   out_mask: Optional[torch.Tensor] = None, out_scale: float = 1.0,
+                   add2: Optional[torch.Tensor] = None, act_out: Optional[torch.Tensor] = None,
+                   act_pre: Optional[torch.Tensor] = None, prelu_w: Optional[torch.Tensor] = None,
+                   want_col_sum: bool = False, out: Optional[torch.Tensor] = None):
+    """dX = epilogue(dy @ w); dy [N,K], w [K,F].  Returns (dx, col_sum | None, prelu_grad | None).
+    See ``magic_proj_epilogue`` in include/magic_hip.h for the epilogue order."""
     lib = load()
     assert dy.dim() == 2 and w.dim() == 2 and dy.shape[1] == w.shape[0]
-    if dy.stride(1) != 1:
-        dy = dy.contiguous()
+    dy = _rows(dy)
     w = w.contiguous()
-    if add is not None and add.stride(1) != 1:
-        add = add.contiguous()
+    add, add2, act_out = _rows(add), _rows(add2), _rows(act_out)
     N, K = dy.shape
     F = w.shape[1]
-    dx = torch.empty(N, F, dtype=torch.float32, device=dy.device)
-    _check(lib.magic_proj_bwd_input(N, K, F, _dev(dy, torch.float32, "dy"), dy.stride(0), _dev(w, torch.float32, "w"),
-                                    _dev(add), add.stride(0) if add is not None else 0, _dev(dx), F, _stream()),
-           "magic_proj_bwd_input")
-    return dx
+    dev = dy.device
+    dx = out if out is not None else torch.empty(N, F, dtype=torch.float32, device=dev)
+    assert dx.stride(1) == 1 and dx.shape == (N, F)
+    col_sum = torch.empty(F, dtype=torch.float32, device=dev) if want_col_sum else None
+    prelu_grad = torch.empty(1, dtype=torch.float32, device=dev) if (act_out is not None and want_col_sum) else None
+    ep = ProjEpilogue()
+    ep.add, ep.ld_add = _dev(add), (add.stride(0) if add is not None else 0)
+    if out_mask is not None:
+        assert out_mask.dtype == torch.uint8 and out_mask.shape == (N, F) and out_mask.is_contiguous()
+    ep.out_mask, ep.out_scale = _dev(out_mask), float(out_scale)
+    ep.add2, ep.ld_add2 = _dev(add2), (add2.stride(0) if add2 is not None else 0)
+    ep.act_out, ep.ld_act = _dev(act_out), (act_out.stride(0) if act_out is not None else 0)
+    if act_pre is not None:
+        assert act_pre.is_contiguous() and act_pre.shape == (N, F)
+    ep.act_pre, ep.prelu_w = _dev(act_pre), _dev(prelu_w)
+    ep.col_sum, ep.prelu_grad = _dev(col_sum), _dev(prelu_grad)
+    nbytes = lib.magic_proj_bwd_input_workspace_bytes(N, K, F) if want_col_sum else 256
+    ws = workspace(nbytes, dev)
+    _check(lib.magic_proj_bwd_input(N, K, F, _dev(dy, torch.float32, "dy"), dy.stride(0),
+                                    _dev(w, torch.float32, "w"), C.byref(ep), _dev(dx), dx.stride(0),
+                                    ws.data_ptr(), ws.numel(), _stream()), "magic_proj_bwd_input")
+    return dx, col_sum, prelu_grad
 
 
-def proj_bwd_weight(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dW = dy.T @ x; dy [N,M], x [N,F] (unit inner strides) -> [M,F]."""
+def proj_bwd_weight(dy: torch.Tensor, x: torch.Tensor, x_mask: Optional[torch.Tensor] = None,
+                    x_scale: float = 1.0) -> torch.Tensor:
+    """dW = dy.T @ (x * mask * scale); dy [N,M], x [N,F] (unit inner strides) -> [M,F]."""
     lib = load()
     assert dy.dim() == 2 and x.dim() == 2 and dy.shape[0] == x.shape[0]
-    if dy.stride(1) != 1:
-        dy = dy.contiguous()
-    if x.stride(1) != 1:
-        x = x.contiguous()
+    dy, x = _rows(dy), _rows(x)
     N, M = dy.shape
     F = x.shape[1]
+    if x_mask is not None:
+        assert x_mask.dtype == torch.uint8 and x_mask.shape == x.shape and x_mask.is_contiguous()
     dw = torch.empty(M, F, dtype=torch.float32, device=dy.device)
     nbytes = lib.magic_proj_bwd_weight_workspace_bytes(N, M, F)
     ws = workspace(nbytes, dy.device)
     _check(lib.magic_proj_bwd_weight(N, M, F, _dev(dy, torch.float32, "dy"), dy.stride(0),
-                                     _dev(x, torch.float32, "x"), x.stride(0), _dev(dw), ws.data_ptr(), ws.numel(),
-                                     _stream()), "magic_proj_bwd_weight")
+                                     _dev(x, torch.float32, "x"), x.stride(0), _dev(x_mask), float(x_scale),
+                                     _dev(dw), ws.data_ptr(), ws.numel(), _stream()), "magic_proj_bwd_weight")
     return dw
 
 
 # ------------------------------------------------------------------------------------- GAT
 def gat_fwd(struct, H: int, D: int, hs, eh, et, ee_table, etype_csc, ee_csc, slope: float, bias, res,
-            prelu_w, want_pre: bool):
+            prelu_w, want_pre: bool, res_mask: Optional[torch.Tensor] = None, res_scale: float = 1.0,
+            out: Optional[torch.Tensor] = None):
+    """``out`` may be a preallocated [N,C] view (unit inner stride, 16-byte aligned rows), e.g. a column
+    block of the concatenated hidden-state buffer.  ``pre`` is only written by the kernel when the
+    PReLU slope is <= 0 (otherwise backward recovers it from ``out``)."""
     lib = load()
     from .graph import LIGHT_MAX
     N, E = struct.num_nodes, struct.num_edges
     dev = hs.device
     Cc = H * D
-    out = torch.empty(N, Cc, dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty(N, Cc, dtype=torch.float32, device=dev)
+    assert out.shape == (N, Cc) and out.stride(1) == 1
     pre = torch.empty(N, Cc, dtype=torch.float32, device=dev) if want_pre else None
     attn = torch.empty(E, H, dtype=torch.float32, device=dev)
     plan = make_plan(struct.plan_in, LIGHT_MAX)
     nbytes = lib.magic_gat_fwd_workspace_bytes(E, struct.plan_in.n_chunks, H, D)
     ws = workspace(nbytes, dev)
+    res = _rows(res)
+    if res_mask is not None:
+        assert res_mask.dtype == torch.uint8 and res_mask.shape == (N, Cc) and res_mask.is_contiguous()
     _check(lib.magic_gat_fwd(N, E, H, D, C.byref(plan), _dev(struct.in_src), _dev(struct.in_dst),
                              _dev(hs, torch.float32, "hs"), hs.stride(0), _dev(eh, torch.float32, "eh"),
                              _dev(et, torch.float32, "et"), eh.stride(0), _dev(ee_table), _dev(etype_csc), _dev(ee_csc),
                              float(slope), _dev(bias), _dev(res), res.stride(0) if res is not None else 0,
-                             _dev(prelu_w), _dev(out), Cc, _dev(pre), _dev(attn),
-                             ws.data_ptr(), ws.numel(), _stream()), "magic_gat_fwd")
+                             _dev(res_mask), float(res_scale), _dev(prelu_w), _dev(out), out.stride(0), _dev(pre),
+                             _dev(attn), ws.data_ptr(), ws.numel(), _stream()), "magic_gat_fwd")
     return out, pre, attn
 
 
-def gat_bwd(struct, H: int, D: int, hs, attn, etype_csc, e_dim: int, slope: float, pre, prelu_w, d_out,
+def gat_bwd(struct, H: int, D: int, hs, attn, etype_csc, e_dim: int, slope: float, pre, act_out, prelu_w, d_out,
             d_pre, d_y, want_bias: bool):
-    """Fills d_pre [N,>=C] and d_y [N,>=C+2H] (views allowed, unit inner stride);
-    returns (d_ee_table | None, edge_rec [E,2H], d_bias | None, d_prelu_w | None)."""
+    """Fills d_pre [N,>=C] and d_y [N,>=C+2H] (views allowed, unit inner stride); with
+    ``prelu_w is None`` ``d_pre`` may be the very tensor passed as ``d_out`` (no copy is made).
+    Returns (d_ee_table | None, edge_rec [E,2H], d_bias | None, d_prelu_w | None)."""
     lib = load()
     from .graph import LIGHT_MAX
     N, E = struct.num_nodes, struct.num_edges
@@ -276,12 +323,13 @@ def gat_bwd(struct, H: int, D: int, hs, attn, etype_csc, e_dim: int, slope: floa
     nbytes = lib.magic_gat_bwd_workspace_bytes(N, E, struct.plan_in.n_chunks, struct.plan_out.n_chunks, H, D,
                                                max(e_dim, 1))
     ws = workspace(nbytes, dev)
-    if d_out.stride(1) != 1:
-        d_out = d_out.contiguous()
+    d_out = _rows(d_out)
+    act_out = _rows(act_out)
     _check(lib.magic_gat_bwd(N, E, H, D, C.byref(pin), _dev(struct.in_src), C.byref(pout), _dev(struct.out_dst),
                              _dev(struct.out_pos), _dev(hs, torch.float32, "hs"), hs.stride(0),
                              _dev(attn, torch.float32, "attn"), _dev(etype_csc), int(e_dim), float(slope),
-                             _dev(pre), _dev(prelu_w), _dev(d_out, torch.float32, "d_out"), d_out.stride(0),
+                             _dev(pre), _dev(act_out), act_out.stride(0) if act_out is not None else 0,
+                             _dev(prelu_w), _dev(d_out, torch.float32, "d_out"), d_out.stride(0),
                              _dev(d_pre), d_pre.stride(0), _dev(d_y), d_y.stride(0), _dev(d_table), _dev(rec),
                              _dev(d_bias), _dev(d_prelu), ws.data_ptr(), ws.numel(), _stream()), "magic_gat_bwd")
     return d_table, rec, d_bias, d_prelu

@@ -21,7 +21,9 @@ struct BwdArgs {
     const int32_t *etype;
     int e_dim;
     float slope;
-    const float *pre;
+    const float *pre;      // [N,C] pre-activation (valid when the slope is <= 0)
+    const float *act_out;  // [N,ld_act] forward output (pre-activation recovered from it when slope > 0)
+    int64_t ld_act;
     const float *prelu_w;
     const float *d_out;
     int64_t ld_dout;
@@ -62,7 +64,17 @@ __global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a) {
     for (int v = blockIdx.x * NPB + slot; v < a.N; v += gridDim.x * NPB) {
         float4 go = ld4(a.d_out + (int64_t)v * a.ld_dout + g * 4);
         if (a.prelu_w) {
-            float4 p = ld4(a.pre + (int64_t)v * C + g * 4);
+            float4 p;
+            if (pw > 0.f) {
+                p = ld4(a.act_out + (int64_t)v * a.ld_act + g * 4);
+                const float iw = 1.f / pw;
+                p.x = p.x > 0.f ? p.x : p.x * iw;
+                p.y = p.y > 0.f ? p.y : p.y * iw;
+                p.z = p.z > 0.f ? p.z : p.z * iw;
+                p.w = p.w > 0.f ? p.w : p.w * iw;
+            } else {
+                p = ld4(a.pre + (int64_t)v * C + g * 4);
+            }
             wsum += (p.x < 0.f ? go.x * p.x : 0.f) + (p.y < 0.f ? go.y * p.y : 0.f) +
                     (p.z < 0.f ? go.z * p.z : 0.f) + (p.w < 0.f ? go.w * p.w : 0.f);
             go.x = p.x > 0.f ? go.x : pw * go.x;
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a) {
             go.z = p.z > 0.f ? go.z : pw * go.z;
             go.w = p.w > 0.f ? go.w : pw * go.w;
         }
-        st4(a.d_pre + (int64_t)v * a.ld_dpre + g * 4, go);
+        if (a.d_pre != a.d_out) st4(a.d_pre + (int64_t)v * a.ld_dpre + g * 4, go);
         add4(bsum, go);
         const int b = a.pin.ptr[v], e = a.pin.ptr[v + 1];
         if (e - b > a.pin.light_max) continue;
@@ -543,7 +555,8 @@ size_t magic_gat_bwd_workspace_bytes(int32_t N, int32_t E, int32_t n_chunks_in, 
 int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_src,
                   const magic_plan *out_plan, const int32_t *out_dst, const int32_t *out_pos, const float *hs,
                   int64_t ld_hs, const float *attn, const int32_t *etype_csc, int32_t e_dim, float slope,
-                  const float *pre, const float *prelu_w, const float *d_out, int64_t ld_dout, float *d_pre,
+                  const float *pre, const float *act_out, int64_t ld_act, const float *prelu_w,
+                  const float *d_out, int64_t ld_dout, float *d_pre,
                   int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table, float *edge_rec, float *d_bias, float *d_prelu_w,
                   void *workspace, size_t workspace_bytes, void *stream_) {
     using namespace magic;
@@ -553,7 +566,8 @@ int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     const int C = H * D;
     if (!plan_valid(in_plan) || !plan_valid(out_plan) || !hs || !d_out || !d_pre || !d_y) return MAGIC_ERR_INVALID_ARG;
     if (E > 0 && (!in_src || !out_dst || !out_pos || !attn || !edge_rec)) return MAGIC_ERR_INVALID_ARG;
-    if (prelu_w && !pre) return MAGIC_ERR_INVALID_ARG;
+    if (prelu_w && (!pre || !act_out || ld_act < C || (ld_act & 3))) return MAGIC_ERR_INVALID_ARG;
+    if (prelu_w && d_pre == d_out) return MAGIC_ERR_INVALID_ARG;  // in-place only without an activation
     if (ld_hs < C || ld_dout < C || ld_dy < C + 2 * H || ld_dpre < C) return MAGIC_ERR_INVALID_ARG;
     if ((ld_hs | ld_dout | ld_dy | ld_dpre) & 3) return MAGIC_ERR_INVALID_ARG;
     if (etype_csc && d_ee_table && (e_dim <= 0 || e_dim > 32)) return MAGIC_ERR_UNSUPPORTED;
@@ -572,6 +586,8 @@ int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     a.e_dim = e_dim;
     a.slope = slope;
     a.pre = pre;
+    a.act_out = act_out;
+    a.ld_act = ld_act;
     a.prelu_w = prelu_w;
     a.d_out = d_out;
     a.ld_dout = ld_dout;

@@ -31,6 +31,8 @@ struct FwdArgs {
     const float *bias;
     const float *res;
     int64_t ld_res;
+    const uint8_t *res_mask;  // [N,C] keep mask of the residual input, or null
+    float res_scale;
     const float *prelu_w;
     float *out;
     int64_t ld_out;
@@ -60,10 +62,21 @@ template <int H, int LPH>
 __device__ __forceinline__ void epilogue(const FwdArgs &a, int v, int g, float4 acc) {
     constexpr int C = H * LPH * 4;
     if (a.bias) add4(acc, ld4(a.bias + g * 4));
-    if (a.res) add4(acc, ld4(a.res + (int64_t)v * a.ld_res + g * 4));
-    if (a.pre) st4(a.pre + (int64_t)v * C + g * 4, acc);
+    if (a.res) {
+        float4 r = ld4(a.res + (int64_t)v * a.ld_res + g * 4);
+        if (a.res_mask) {  // residual input = dropout(input): keep mask applied on the fly
+            const uchar4 m = *reinterpret_cast<const uchar4 *>(a.res_mask + (int64_t)v * C + g * 4);
+            r.x = m.x ? r.x * a.res_scale : 0.f;
+            r.y = m.y ? r.y * a.res_scale : 0.f;
+            r.z = m.z ? r.z * a.res_scale : 0.f;
+            r.w = m.w ? r.w * a.res_scale : 0.f;
+        }
+        add4(acc, r);
+    }
     if (a.prelu_w) {
         float w = a.prelu_w[0];
+        // with a positive slope the backward pass recovers the pre-activation from the output
+        if (a.pre && !(w > 0.f)) st4(a.pre + (int64_t)v * C + g * 4, acc);
         acc.x = acc.x >= 0.f ? acc.x : w * acc.x;
         acc.y = acc.y >= 0.f ? acc.y : w * acc.y;
         acc.z = acc.z >= 0.f ? acc.z : w * acc.z;
@@ -334,7 +347,8 @@ size_t magic_gat_fwd_workspace_bytes(int32_t n_edges, int32_t n_chunks, int32_t 
 int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_src,
                   const int32_t *in_dst, const float *hs, int64_t ld_hs, const float *eh, const float *et,
                   int64_t ld_score, const float *ee_table, const int32_t *etype_csc, const float *ee_csc,
-                  float slope, const float *bias, const float *res, int64_t ld_res, const float *prelu_w,
+                  float slope, const float *bias, const float *res, int64_t ld_res, const uint8_t *res_mask,
+                  float res_scale, const float *prelu_w,
                   float *out, int64_t ld_out, float *pre, float *attn, void *workspace, size_t workspace_bytes,
                   void *stream_) {
     using namespace magic;
@@ -367,6 +381,8 @@ int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     a.bias = bias;
     a.res = res;
     a.ld_res = ld_res;
+    a.res_mask = res ? res_mask : nullptr;
+    a.res_scale = res_scale;
     a.prelu_w = prelu_w;
     a.out = out;
     a.ld_out = ld_out;

@@ -1,22 +1,27 @@
-// Dense node projection  Y = X . W^T  in exact fp32 on the matrix cores
-// (v_mfma_f32_32x32x2_f32: bit-equal to an fmaf chain over k), with the output columns
-// routed to three destinations: the gathered operand hs (kept in its own 128-byte aligned
-// rows), the 2H attention score columns, and the residual projection.
+// Dense node projection  Y = (X (.) mask) . op(W)  in exact fp32 on the matrix cores
+// (v_mfma_f32_32x32x2_f32: bit-equal to an fmaf chain over k), with a fused epilogue.
 //
-// Block = 4 waves = 128 input rows x all M output columns; K is walked in chunks of 32
-// staged through LDS.  Operand map of the 32x32x2 MFMA (lane l): A[i = l&31][k = l>>5],
-// B[k = l>>5][j = l&31], D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].  Inside a chunk the
-// K index is permuted so that lane half (l>>5) owns 16 contiguous k: A and B use the same
-// permutation, which only reorders the k-sum.  The kernel is HBM-bound (N*(F+M)*4 bytes
-// against 2*N*F*M flops with F, M <= 264), so the tile is sized for streaming, not reuse.
+// Forward use: output columns are routed to three destinations -- the gathered operand hs
+// (own buffer, 16-byte aligned rows), the 2H attention score columns, the residual projection.
+// Backward use (dX = dY . W): the epilogue chains, per element of the hs columns,
+//     v = acc  (+ add)  (* out_mask * out_scale)  (+ add2)  (* PReLU'(pre))  -> store
+// and accumulates the column sums of the stored values (bias gradient) and the PReLU slope
+// gradient, so that the gradient w.r.t. the previous layer's pre-activation leaves this kernel
+// ready for the sparse backward sweeps.
+//
+// Operand map of the 32x32x2 MFMA (lane l): A[i = l&31][k = l>>5], B[k = l>>5][j = l&31],
+// D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].  Inside a 32-wide K chunk the K index is
+// permuted so that lane half (l>>5) owns 16 contiguous k: A and B use the same permutation,
+// which only reorders the k-sum.  All variants are HBM-bound (4N(F+M) bytes against 2NFM
+// flops with F, M <= a few hundred): tiles are sized for streaming, not for reuse.
 #include "common.h"
 
 namespace {
 
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;   // rows per block
-constexpr int KC = 32;    // k per LDS chunk
+constexpr int BM = 128;     // rows per block (block-tile variant)
+constexpr int KC = 32;      // k per LDS chunk
 constexpr int LDS_LD = 36;  // floats per staged row (144 B)
 
 struct ProjArgs {
@@ -24,24 +29,177 @@ struct ProjArgs {
     int F, M, C, NS, RC;
     const float *x;
     int64_t ld_x;
+    const uint8_t *x_mask;  // [N,F] keep mask on X (dropout), or null
+    float x_scale;
     const float *w;
     int64_t w_rs, w_cs;  // element (row r, k) of the weight = w[r * w_rs + k * w_cs]
     int col0;            // first output column of this launch (wide outputs take several)
-    const float *add;    // optional [N, ld_add] added to the hs columns
-    int64_t ld_add;
     const char *name;
     float *hs;
     int64_t ld_hs;
     float *score;
     float *res;
     int64_t ld_res;
+    // epilogue chain on the hs columns
+    const float *add;
+    int64_t ld_add;
+    const uint8_t *out_mask;  // [N,C]
+    float out_scale;
+    const float *add2;
+    int64_t ld_add2;
+    const float *act_out;  // forward output of the layer whose PReLU is differentiated
+    int64_t ld_act;
+    const float *act_pre;  // [N,C] its pre-activation (read only when the slope is <= 0)
+    const float *prelu_w;  // device scalar
+    float *part_col;       // [n_part, C] per-wave column sums (or null)
+    float *part_prelu;     // [n_part]
 };
 
-template <int NCT>  // number of 32-column tiles
+struct Sums {
+    float col;    // running column sum of this lane's column (current column tile)
+    float prelu;  // running slope gradient
+};
+
+// value -> epilogue chain for one element of an hs column; returns the stored value
+__device__ __forceinline__ float chain(const ProjArgs &a, float v, int64_t row, int col, float w, float &dprelu) {
+    if (a.add) v += a.add[row * a.ld_add + col];
+    if (a.out_mask) v = a.out_mask[row * a.C + col] ? v * a.out_scale : 0.f;
+    if (a.add2) v += a.add2[row * a.ld_add2 + col];
+    if (a.act_out) {
+        const float o = a.act_out[row * a.ld_act + col];
+        float pre;
+        if (w > 0.f)
+            pre = o > 0.f ? o : o / w;  // PReLU is invertible for a positive slope
+        else
+            pre = a.act_pre[row * a.C + col];
+        if (!(pre > 0.f)) {
+            dprelu = fmaf(v, pre, dprelu);
+            v *= w;
+        }
+    }
+    return v;
+}
+
+__device__ __forceinline__ float4 load_x4(const ProjArgs &a, int64_t row, int c, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < a.n && c < a.F) {
+        const float *p = a.x + row * a.ld_x + c;
+        if (vec && c + 3 < a.F) {
+            v = *reinterpret_cast<const float4 *>(p);
+        } else {
+            v.x = p[0];
+            if (c + 1 < a.F) v.y = p[1];
+            if (c + 2 < a.F) v.z = p[2];
+            if (c + 3 < a.F) v.w = p[3];
+        }
+        if (a.x_mask) {
+            const uint8_t *m = a.x_mask + row * a.F + c;
+            v.x = m[0] ? v.x * a.x_scale : 0.f;
+            if (c + 1 < a.F) v.y = m[1] ? v.y * a.x_scale : 0.f;
+            if (c + 2 < a.F) v.z = m[2] ? v.z * a.x_scale : 0.f;
+            if (c + 3 < a.F) v.w = m[3] ? v.w * a.x_scale : 0.f;
+        }
+    }
+    return v;
+}
+
+__device__ __forceinline__ float4 load_w4(const ProjArgs &a, int r, int c, bool wvec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.col0 + r < a.M && c < a.F) {
+        const float *p = a.w + (int64_t)(a.col0 + r) * a.w_rs + (int64_t)c * a.w_cs;
+        if (wvec && c + 3 < a.F) {
+            v = *reinterpret_cast<const float4 *>(p);
+        } else {
+            v.x = p[0];
+            if (c + 1 < a.F) v.y = p[a.w_cs];
+            if (c + 2 < a.F) v.z = p[2 * a.w_cs];
+            if (c + 3 < a.F) v.w = p[3 * a.w_cs];
+        }
+    }
+    return v;
+}
+
+// Store one 32x32 accumulator tile (rows t_row0 + map(r, hf), column c_lo + lr) through the
+// epilogue; `csum` collects the column sum of the stored hs values, `dprelu` the slope gradient.
+__device__ __forceinline__ void store_tile(const ProjArgs &a, const float16_t &acc, int64_t row0, int c_lo, int lr,
+                                           int hf, float w, float &csum, float &dprelu) {
+    const int col = c_lo + lr;
+    const bool full_rows = row0 + 32 <= a.n;  // wave-uniform
+    const bool plain = !a.add && !a.out_mask && !a.add2 && !a.act_out && !a.part_col;
+    if (full_rows && c_lo + 32 <= a.C) {  // whole tile in hs
+        float *p = a.hs + (row0 + 4 * hf) * a.ld_hs + col;
+        if (plain) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * a.ld_hs] = acc[r];
+        } else {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                v[r] = chain(a, acc[r], row0 + 4 * hf + (r & 3) + 8 * (r >> 2), col, w, dprelu);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[((r & 3) + 8 * (r >> 2)) * a.ld_hs] = v[r];
+                csum += v[r];
+            }
+        }
+        return;
+    }
+    if (full_rows && c_lo >= a.C + a.NS && c_lo + 32 <= a.M) {  // whole tile in res
+        float *p = a.res + (row0 + 4 * hf) * a.ld_res + (col - a.C - a.NS);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * a.ld_res] = acc[r];
+        return;
+    }
+    const int c_hi = c_lo + 32 < a.M ? c_lo + 32 : a.M;
+    if (full_rows && c_lo >= a.C && c_hi <= a.C + a.NS) {  // tile holds score columns only
+        if (col < c_hi) {
+            float *p = a.score + (row0 + 4 * hf) * a.NS + (col - a.C);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * a.NS] = acc[r];
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        if (row >= a.n) continue;
+        if (col < a.C) {
+            const float v = plain ? acc[r] : chain(a, acc[r], row, col, w, dprelu);
+            a.hs[row * a.ld_hs + col] = v;
+            csum += v;
+        } else if (col < a.C + a.NS) {
+            a.score[row * a.NS + (col - a.C)] = acc[r];
+        } else if (col < a.M) {
+            a.res[row * a.ld_res + (col - a.C - a.NS)] = acc[r];
+        }
+    }
+}
+
+// per-wave partial sums -> workspace rows (one row per wave of the grid)
+template <int NCT>
+__device__ __forceinline__ void flush_sums(const ProjArgs &a, const float (&csum)[NCT], float dprelu, int lane) {
+    if (!a.part_col) return;
+    const int64_t prow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        float v = csum[ct] + __shfl_xor(csum[ct], 32, 64);  // the two lane halves hold the same column
+        const int col = a.col0 + ct * 32 + (lane & 31);
+        if (lane < 32 && col < a.C) a.part_col[prow * a.C + col] = v;
+    }
+    if (a.part_prelu) {
+        float v = dprelu;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) a.part_prelu[prow] = v;
+    }
+}
+
+// ---- block-tile variant: 4 waves = 128 rows x all columns, K chunks staged through LDS -------
+template <int NCT>
 __global__ __launch_bounds__(256) void k_proj(ProjArgs a) {
     extern __shared__ __align__(16) float sm[];
-    float *xs = sm;                  // [BM][LDS_LD]
-    float *ws = sm + BM * LDS_LD;    // [NCT*32][LDS_LD]
+    float *xs = sm;                // [BM][LDS_LD]
+    float *ws = sm + BM * LDS_LD;  // [NCT*32][LDS_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hf = lane >> 5, lr = lane & 31;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
@@ -52,43 +210,15 @@ __global__ __launch_bounds__(256) void k_proj(ProjArgs a) {
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
     const bool vec = (a.F % 4 == 0) && (a.ld_x % 4 == 0) && ((uintptr_t)a.x % 16 == 0);
     const bool wvec = (a.F % 4 == 0) && a.w_cs == 1 && (a.w_rs % 4 == 0) && ((uintptr_t)a.w % 16 == 0);
-
     for (int k0 = 0; k0 < a.F; k0 += KC) {
         __syncthreads();
-        // stage X chunk: BM rows x KC floats
         for (int idx = tid; idx < BM * (KC / 4); idx += 256) {
-            int r = idx / (KC / 4), c4 = (idx % (KC / 4)) * 4;
-            int64_t row = row0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < a.n) {
-                const float *p = a.x + row * a.ld_x + k0 + c4;
-                if (vec && k0 + c4 + 3 < a.F) {
-                    v = *reinterpret_cast<const float4 *>(p);
-                } else {
-                    if (k0 + c4 + 0 < a.F) v.x = p[0];
-                    if (k0 + c4 + 1 < a.F) v.y = p[1];
-                    if (k0 + c4 + 2 < a.F) v.z = p[2];
-                    if (k0 + c4 + 3 < a.F) v.w = p[3];
-                }
-            }
-            *reinterpret_cast<float4 *>(xs + r * LDS_LD + c4) = v;
+            const int r = idx / (KC / 4), c4 = (idx % (KC / 4)) * 4;
+            *reinterpret_cast<float4 *>(xs + r * LDS_LD + c4) = load_x4(a, row0 + r, k0 + c4, vec);
         }
-        // stage W chunk: NCT*32 output channels x KC floats
         for (int idx = tid; idx < NCT * 32 * (KC / 4); idx += 256) {
-            int r = idx / (KC / 4), c4 = (idx % (KC / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.col0 + r < a.M) {
-                const float *p = a.w + (int64_t)(a.col0 + r) * a.w_rs + (int64_t)(k0 + c4) * a.w_cs;
-                if (wvec && k0 + c4 + 3 < a.F) {
-                    v = *reinterpret_cast<const float4 *>(p);
-                } else {
-                    if (k0 + c4 + 0 < a.F) v.x = p[0];
-                    if (k0 + c4 + 1 < a.F) v.y = p[a.w_cs];
-                    if (k0 + c4 + 2 < a.F) v.z = p[2 * a.w_cs];
-                    if (k0 + c4 + 3 < a.F) v.w = p[3 * a.w_cs];
-                }
-            }
-            *reinterpret_cast<float4 *>(ws + r * LDS_LD + c4) = v;
+            const int r = idx / (KC / 4), c4 = (idx % (KC / 4)) * 4;
+            *reinterpret_cast<float4 *>(ws + r * LDS_LD + c4) = load_w4(a, r, k0 + c4, wvec);
         }
         __syncthreads();
         float af[16];
@@ -119,36 +249,26 @@ __global__ __launch_bounds__(256) void k_proj(ProjArgs a) {
             for (int s = 0; s < 16; ++s) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc[ct], 0, 0, 0);
         }
     }
-    // epilogue: route columns
+    const float w = a.prelu_w ? a.prelu_w[0] : 1.f;
+    float csum[NCT];
+    float dprelu = 0.f;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        const int col = a.col0 + ct * 32 + lr;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            if (row >= a.n) continue;
-            float v = acc[ct][r];
-            if (col < a.C) {
-                if (a.add) v += a.add[row * a.ld_add + col];
-                a.hs[row * a.ld_hs + col] = v;
-            } else if (col < a.C + a.NS) {
-                a.score[row * a.NS + (col - a.C)] = v;
-            } else if (col < a.M) {
-                a.res[row * a.ld_res + (col - a.C - a.NS)] = v;
-            }
-        }
+        csum[ct] = 0.f;
+        store_tile(a, acc[ct], row0 + wave * 32, a.col0 + ct * 32, lr, hf, w, csum[ct], dprelu);
     }
+    flush_sums<NCT>(a, csum, dprelu, lane);
 }
 
-// Streaming variant for K <= 32*KCH small enough that the whole weight block fits in LDS:
-// W is staged once per block; afterwards the four waves are independent -- each walks 32-row
-// tiles, copies its tile through a private LDS strip with coalesced 16-byte loads (the next
-// tile's loads are issued before the current tile's MFMAs), and never meets a block barrier.
+// ---- streaming variant: the whole weight block stays in LDS; the four waves are independent,
+// each walks 32-row tiles, copies its tile through a private LDS strip with coalesced 16-byte
+// loads (the next tile's loads are issued before the current tile's MFMAs) and never meets a
+// block barrier after the weight staging.
 template <int NCT, int KCH>
 __global__ __launch_bounds__(256) void k_proj_stream(ProjArgs a) {
     constexpr int KP = KCH * 32;
-    constexpr int LDW = KP + 4;          // 16-B aligned rows, 4-bank skew between rows
-    constexpr int NV = KP / 8;           // float4 per lane per tile
+    constexpr int LDW = KP + 4;  // 16-B aligned rows, 4-bank skew between rows
+    constexpr int NV = KP / 8;   // float4 per lane per tile
     extern __shared__ __align__(16) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hf = lane >> 5, lr = lane & 31;
@@ -157,44 +277,24 @@ __global__ __launch_bounds__(256) void k_proj_stream(ProjArgs a) {
     const bool wvec = (a.F % 4 == 0) && a.w_cs == 1 && (a.w_rs % 4 == 0) && ((uintptr_t)a.w % 16 == 0);
     for (int idx = tid; idx < NCT * 32 * (KP / 4); idx += 256) {
         const int r = idx / (KP / 4), c4 = (idx % (KP / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.col0 + r < a.M) {
-            const float *p = a.w + (int64_t)(a.col0 + r) * a.w_rs + (int64_t)c4 * a.w_cs;
-            if (wvec && c4 + 3 < a.F) {
-                v = *reinterpret_cast<const float4 *>(p);
-            } else {
-                if (c4 + 0 < a.F) v.x = p[0];
-                if (c4 + 1 < a.F) v.y = p[a.w_cs];
-                if (c4 + 2 < a.F) v.z = p[2 * a.w_cs];
-                if (c4 + 3 < a.F) v.w = p[3 * a.w_cs];
-            }
-        }
-        *reinterpret_cast<float4 *>(ws + r * LDW + c4) = v;
+        *reinterpret_cast<float4 *>(ws + r * LDW + c4) = load_w4(a, r, c4, wvec);
     }
     __syncthreads();
     const bool vec = (a.F % 4 == 0) && (a.ld_x % 4 == 0) && ((uintptr_t)a.x % 16 == 0);
     const int64_t n_tiles = (a.n + 31) / 32;
     const int64_t t_stride = (int64_t)gridDim.x * 4;
+    const float w = a.prelu_w ? a.prelu_w[0] : 1.f;
+    float csum[NCT];
+    float dprelu = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) csum[ct] = 0.f;
     float4 v[NV];
     auto load_tile = [&](int64_t t) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = lane + 64 * i;
             const int r = idx / (KP / 4), c4 = (idx % (KP / 4)) * 4;
-            const int64_t row = t * 32 + r;
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < a.n && c4 < a.F) {
-                const float *p = a.x + row * a.ld_x + c4;
-                if (vec && c4 + 3 < a.F) {
-                    q = *reinterpret_cast<const float4 *>(p);
-                } else {
-                    q.x = p[0];
-                    if (c4 + 1 < a.F) q.y = p[1];
-                    if (c4 + 2 < a.F) q.z = p[2];
-                    if (c4 + 3 < a.F) q.w = p[3];
-                }
-            }
-            v[i] = q;
+            v[i] = load_x4(a, t * 32 + r, c4, vec);
         }
     };
     int64_t t = (int64_t)blockIdx.x * 4 + wave;
@@ -208,7 +308,7 @@ __global__ __launch_bounds__(256) void k_proj_stream(ProjArgs a) {
             *reinterpret_cast<float4 *>(xs + r * LDW + c4) = v[i];
         }
         __builtin_amdgcn_wave_barrier();
-        if (t + t_stride < n_tiles) load_tile(t + t_stride);   // in flight behind the MFMAs below
+        if (t + t_stride < n_tiles) load_tile(t + t_stride);  // in flight behind the MFMAs below
         float16_t acc[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
@@ -245,80 +345,60 @@ __global__ __launch_bounds__(256) void k_proj_stream(ProjArgs a) {
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc[ct], 0, 0, 0);
             }
         }
-        const bool full_rows = t * 32 + 32 <= a.n;   // wave-uniform
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const int c_lo = a.col0 + ct * 32;
-            const int col = c_lo + lr;
-            // whole column tile inside one destination and all 32 rows valid: plain strided stores
-            float *dst = nullptr;
-            int64_t ld = 0;
-            if (full_rows) {
-                if (c_lo + 32 <= a.C) {
-                    dst = a.hs + col;
-                    ld = a.ld_hs;
-                } else if (c_lo >= a.C + a.NS && c_lo + 32 <= a.M) {
-                    dst = a.res + (col - a.C - a.NS);
-                    ld = a.ld_res;
-                }
-            }
-            if (dst) {
-                float *p = dst + (t * 32 + 4 * hf) * ld;
-                if (a.add && c_lo + 32 <= a.C) {
-                    const float *q = a.add + (t * 32 + 4 * hf) * a.ld_add + col;
-                    float ad[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) ad[r] = q[((r & 3) + 8 * (r >> 2)) * a.ld_add];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * ld] = acc[ct][r] + ad[r];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * ld] = acc[ct][r];
-                }
-                continue;
-            }
-            const int c_hi = c_lo + 32 < a.M ? c_lo + 32 : a.M;
-            if (full_rows && c_lo >= a.C && c_hi <= a.C + a.NS) {  // tile holds score columns only
-                if (col < c_hi) {
-                    float *p = a.score + (t * 32 + 4 * hf) * a.NS + (col - a.C);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * a.NS] = acc[ct][r];
-                }
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                if (row >= a.n) continue;
-                float val = acc[ct][r];
-                if (col < a.C) {
-                    if (a.add) val += a.add[row * a.ld_add + col];
-                    a.hs[row * a.ld_hs + col] = val;
-                } else if (col < a.C + a.NS) {
-                    a.score[row * a.NS + (col - a.C)] = val;
-                } else if (col < a.M) {
-                    a.res[row * a.ld_res + (col - a.C - a.NS)] = val;
-                }
-            }
+        for (int ct = 0; ct < NCT; ++ct)
+            store_tile(a, acc[ct], t * 32, a.col0 + ct * 32, lr, hf, w, csum[ct], dprelu);
+    }
+    flush_sums<NCT>(a, csum, dprelu, lane);
+}
+
+// fixed-order reduction of the per-wave partial rows: block c < C sums column c, block C the
+// PReLU partials (256 threads take rows round robin, then a tree)
+__global__ __launch_bounds__(256) void k_proj_sums(const float *part_col, const float *part_prelu, int n_part, int C,
+                                                   float *col_sum, float *prelu_grad) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float t = 0.f;
+    if (c < C) {
+        for (int k = threadIdx.x; k < n_part; k += 256) t += part_col[(int64_t)k * C + c];
+    } else {
+        for (int k = threadIdx.x; k < n_part; k += 256) t += part_prelu[k];
+    }
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (c < C) {
+            if (col_sum) col_sum[c] = red[0];
+        } else if (prelu_grad) {
+            prelu_grad[0] = red[0];
         }
     }
 }
 
+size_t stream_lds(int nct, int kch) { return (size_t)(nct * 32 + 4 * 32) * (kch * 32 + 4) * sizeof(float); }
+
+int stream_grid(const ProjArgs &a, int nct, int kch) {
+    size_t sh = stream_lds(nct, kch);
+    int64_t tiles = (a.n + 31) / 32;
+    int blocks_per_cu = sh <= 40 * 1024 ? 4 : (sh <= 80 * 1024 ? 2 : 1);
+    int64_t want = (tiles + 3) / 4;
+    int64_t cap = 256 * blocks_per_cu;
+    return (int)(want < cap ? want : cap);
+}
+
 template <int NCT, int KCH> int launch_stream(const ProjArgs &a, hipStream_t stream) {
-    constexpr int LDW = KCH * 32 + 4;
-    size_t sh = (size_t)(NCT * 32 + 4 * 32) * LDW * sizeof(float);
+    size_t sh = stream_lds(NCT, KCH);
     static bool attr_set = false;
     if (sh > 48 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute((const void *)k_proj_stream<NCT, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sh);
         attr_set = true;
     }
-    int64_t tiles = (a.n + 31) / 32;
-    int blocks_per_cu = sh <= 40 * 1024 ? 4 : (sh <= 80 * 1024 ? 2 : 1);
-    int64_t want = (tiles + 3) / 4;
-    int64_t cap = 256 * blocks_per_cu;
-    unsigned grid = (unsigned)(want < cap ? want : cap);
-    MAGIC_LAUNCH(a.name, (k_proj_stream<NCT, KCH>), grid, 256, sh, stream, a);
+    MAGIC_LAUNCH(a.name, (k_proj_stream<NCT, KCH>), stream_grid(a, NCT, KCH), 256, sh, stream, a);
     return magic::launch_status();
 }
 
@@ -326,7 +406,15 @@ template <int NCT, int KCH> int launch_stream(const ProjArgs &a, hipStream_t str
 #define MAGIC_PROJ_STREAM_SHAPES(X) \
     X(5, 1) X(3, 2) X(2, 6) X(1, 2) X(2, 1) X(6, 2) X(2, 3) X(1, 5) X(1, 1) X(2, 2) X(3, 1) X(4, 1) X(8, 1)
 
-template <int NCT> int launch(const ProjArgs &a, hipStream_t stream) {
+bool has_stream(int nct, int kch) {
+#define X(n, k) \
+    if (nct == n && kch == k) return true;
+    MAGIC_PROJ_STREAM_SHAPES(X)
+#undef X
+    return false;
+}
+
+template <int NCT> int launch_block(const ProjArgs &a, hipStream_t stream) {
     size_t sh = (size_t)(BM + NCT * 32) * LDS_LD * sizeof(float);
     unsigned grid = (unsigned)((a.n + BM - 1) / BM);
     static bool attr_set = false;
@@ -338,75 +426,6 @@ template <int NCT> int launch(const ProjArgs &a, hipStream_t stream) {
     return magic::launch_status();
 }
 
-int dispatch(const ProjArgs &a, hipStream_t stream);
-
-}  // namespace
-
-extern "C" {
-
-int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_score, int32_t res_c, const float *x,
-                   int64_t ld_x, const float *w, float *hs, int64_t ld_hs, float *score, float *res, int64_t ld_res,
-                   void *stream_) {
-    if (n_rows < 0 || in_dim <= 0 || out_c <= 0 || n_score < 0 || res_c < 0) return MAGIC_ERR_INVALID_ARG;
-    if (n_rows == 0) return MAGIC_OK;
-    if (!x || !w || !hs || ld_x < in_dim || ld_hs < out_c) return MAGIC_ERR_INVALID_ARG;
-    if ((n_score > 0 && !score) || (res_c > 0 && (!res || ld_res < res_c))) return MAGIC_ERR_INVALID_ARG;
-    ProjArgs a;
-    a.n = n_rows;
-    a.F = in_dim;
-    a.C = out_c;
-    a.NS = n_score;
-    a.RC = res_c;
-    a.M = out_c + n_score + res_c;
-    a.x = x;
-    a.ld_x = ld_x;
-    a.w = w;
-    a.w_rs = in_dim;
-    a.w_cs = 1;
-    a.add = nullptr;
-    a.ld_add = 0;
-    a.name = "proj_fwd_mfma_f32";
-    a.hs = hs;
-    a.ld_hs = ld_hs;
-    a.score = score;
-    a.res = res;
-    a.ld_res = ld_res;
-    hipStream_t stream = (hipStream_t)stream_;
-    return dispatch(a, stream);
-}
-
-int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim, const float *dy, int64_t ld_dy,
-                         const float *w, const float *add, int64_t ld_add, float *dx, int64_t ld_dx,
-                         void *stream_) {
-    if (n_rows < 0 || k_dim <= 0 || out_dim <= 0) return MAGIC_ERR_INVALID_ARG;
-    if (n_rows == 0) return MAGIC_OK;
-    if (!dy || !w || !dx || ld_dy < k_dim || ld_dx < out_dim || (add && ld_add < out_dim)) return MAGIC_ERR_INVALID_ARG;
-    ProjArgs a;
-    a.n = n_rows;
-    a.F = k_dim;       // reduction runs over the columns of dY
-    a.C = out_dim;
-    a.NS = 0;
-    a.RC = 0;
-    a.M = out_dim;
-    a.x = dy;
-    a.ld_x = ld_dy;
-    a.w = w;           // [k_dim, out_dim] row-major, read transposed
-    a.w_rs = 1;
-    a.w_cs = out_dim;
-    a.add = add;
-    a.ld_add = ld_add;
-    a.name = "proj_bwd_input_mfma_f32";
-    a.hs = dx;
-    a.ld_hs = ld_dx;
-    a.score = nullptr;
-    a.res = nullptr;
-    a.ld_res = 0;
-    return dispatch(a, (hipStream_t)stream_);
-}
-
-}  // extern "C"
-
-namespace {
 int dispatch_one(const ProjArgs &a, int nct, hipStream_t stream) {
     const int kch = (a.F + 31) / 32;
 #define X(n, k) \
@@ -414,18 +433,25 @@ int dispatch_one(const ProjArgs &a, int nct, hipStream_t stream) {
     MAGIC_PROJ_STREAM_SHAPES(X)
 #undef X
     switch (nct) {
-        case 1: return launch<1>(a, stream);
-        case 2: return launch<2>(a, stream);
-        case 3: return launch<3>(a, stream);
-        case 4: return launch<4>(a, stream);
-        case 5: return launch<5>(a, stream);
-        case 6: return launch<6>(a, stream);
-        case 7: return launch<7>(a, stream);
-        case 8: return launch<8>(a, stream);
-        case 9: return launch<9>(a, stream);
-        case 10: return launch<10>(a, stream);
+        case 1: return launch_block<1>(a, stream);
+        case 2: return launch_block<2>(a, stream);
+        case 3: return launch_block<3>(a, stream);
+        case 4: return launch_block<4>(a, stream);
+        case 5: return launch_block<5>(a, stream);
+        case 6: return launch_block<6>(a, stream);
+        case 7: return launch_block<7>(a, stream);
+        case 8: return launch_block<8>(a, stream);
+        case 9: return launch_block<9>(a, stream);
+        case 10: return launch_block<10>(a, stream);
         default: return MAGIC_ERR_UNSUPPORTED;
     }
+}
+
+// number of partial rows (= waves of the grid) one launch over `nct` column tiles writes
+int64_t n_partials(const ProjArgs &a, int nct) {
+    const int kch = (a.F + 31) / 32;
+    if (has_stream(nct, kch)) return (int64_t)stream_grid(a, nct, kch) * 4;
+    return ((a.n + BM - 1) / BM) * 4;
 }
 
 // up to 10 column tiles (320 outputs) per launch; wider outputs take several launches of 8
@@ -443,4 +469,130 @@ int dispatch(const ProjArgs &a0, hipStream_t stream) {
     }
     return MAGIC_OK;
 }
+
+void init_args(ProjArgs &a) {
+    a.x_mask = nullptr;
+    a.x_scale = 1.f;
+    a.col0 = 0;
+    a.score = nullptr;
+    a.res = nullptr;
+    a.ld_res = 0;
+    a.NS = 0;
+    a.RC = 0;
+    a.add = nullptr;
+    a.ld_add = 0;
+    a.out_mask = nullptr;
+    a.out_scale = 1.f;
+    a.add2 = nullptr;
+    a.ld_add2 = 0;
+    a.act_out = nullptr;
+    a.ld_act = 0;
+    a.act_pre = nullptr;
+    a.prelu_w = nullptr;
+    a.part_col = nullptr;
+    a.part_prelu = nullptr;
+}
+
 }  // namespace
+
+extern "C" {
+
+int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_score, int32_t res_c, const float *x,
+                   int64_t ld_x, const uint8_t *x_mask, float x_scale, const float *w, float *hs, int64_t ld_hs,
+                   float *score, float *res, int64_t ld_res, void *stream_) {
+    if (n_rows < 0 || in_dim <= 0 || out_c <= 0 || n_score < 0 || res_c < 0) return MAGIC_ERR_INVALID_ARG;
+    if (n_rows == 0) return MAGIC_OK;
+    if (!x || !w || !hs || ld_x < in_dim || ld_hs < out_c) return MAGIC_ERR_INVALID_ARG;
+    if ((n_score > 0 && !score) || (res_c > 0 && (!res || ld_res < res_c))) return MAGIC_ERR_INVALID_ARG;
+    ProjArgs a;
+    init_args(a);
+    a.n = n_rows;
+    a.F = in_dim;
+    a.C = out_c;
+    a.NS = n_score;
+    a.RC = res_c;
+    a.M = out_c + n_score + res_c;
+    a.x = x;
+    a.ld_x = ld_x;
+    a.x_mask = x_mask;
+    a.x_scale = x_scale;
+    a.w = w;
+    a.w_rs = in_dim;
+    a.w_cs = 1;
+    a.name = "proj_fwd_mfma_f32";
+    a.hs = hs;
+    a.ld_hs = ld_hs;
+    a.score = score;
+    a.res = res;
+    a.ld_res = ld_res;
+    return dispatch(a, (hipStream_t)stream_);
+}
+
+size_t magic_proj_bwd_input_workspace_bytes(int64_t n_rows, int32_t k_dim, int32_t out_dim) {
+    if (n_rows <= 0 || k_dim <= 0 || out_dim <= 0) return 256;
+    ProjArgs a;
+    init_args(a);
+    a.n = n_rows;
+    a.F = k_dim;
+    a.M = a.C = out_dim;
+    const int tiles = (out_dim + 31) / 32;
+    int64_t np = tiles <= 10 ? n_partials(a, tiles) : n_partials(a, 8);
+    return magic::align_up((size_t)np * out_dim * sizeof(float)) + magic::align_up((size_t)np * sizeof(float)) + 256;
+}
+
+int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim, const float *dy, int64_t ld_dy,
+                         const float *w, const magic_proj_epilogue *ep, float *dx, int64_t ld_dx, void *workspace,
+                         size_t workspace_bytes, void *stream_) {
+    if (n_rows < 0 || k_dim <= 0 || out_dim <= 0) return MAGIC_ERR_INVALID_ARG;
+    if (n_rows == 0) return MAGIC_OK;
+    if (!dy || !w || !dx || ld_dy < k_dim || ld_dx < out_dim) return MAGIC_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    ProjArgs a;
+    init_args(a);
+    a.n = n_rows;
+    a.F = k_dim;  // the reduction runs over the columns of dY
+    a.C = a.M = out_dim;
+    a.x = dy;
+    a.ld_x = ld_dy;
+    a.w = w;  // [k_dim, out_dim] row-major, read transposed
+    a.w_rs = 1;
+    a.w_cs = out_dim;
+    a.name = "proj_bwd_input_mfma_f32";
+    a.hs = dx;
+    a.ld_hs = ld_dx;
+    bool sums = false;
+    if (ep) {
+        if ((ep->add && ep->ld_add < out_dim) || (ep->add2 && ep->ld_add2 < out_dim)) return MAGIC_ERR_INVALID_ARG;
+        if (ep->act_out && (!ep->prelu_w || !ep->act_pre || ep->ld_act < out_dim)) return MAGIC_ERR_INVALID_ARG;
+        a.add = ep->add;
+        a.ld_add = ep->ld_add;
+        a.out_mask = ep->out_mask;
+        a.out_scale = ep->out_scale;
+        a.add2 = ep->add2;
+        a.ld_add2 = ep->ld_add2;
+        a.act_out = ep->act_out;
+        a.ld_act = ep->ld_act;
+        a.act_pre = ep->act_pre;
+        a.prelu_w = ep->act_out ? ep->prelu_w : nullptr;
+        sums = ep->col_sum != nullptr || ep->prelu_grad != nullptr;
+    }
+    int64_t np = 0;
+    if (sums) {
+        const int tiles = (out_dim + 31) / 32;
+        if (tiles > 10) return MAGIC_ERR_UNSUPPORTED;  // column sums need a single launch
+        np = n_partials(a, tiles);
+        magic::Arena ar(workspace, workspace_bytes);
+        a.part_col = ar.take<float>((size_t)np * out_dim);
+        a.part_prelu = ar.take<float>((size_t)np);
+        if (!ar.ok() || !a.part_col || !a.part_prelu) return MAGIC_ERR_WORKSPACE;
+    }
+    int st = dispatch(a, stream);
+    if (st != MAGIC_OK) return st;
+    if (sums) {
+        MAGIC_LAUNCH("proj_bwd_input_sums", k_proj_sums, out_dim + 1, 256, 0, stream, a.part_col, a.part_prelu, (int)np,
+                     out_dim, ep->col_sum, ep->prelu_grad);
+    }
+    return magic::launch_status();
+}
+
+}  // extern "C"

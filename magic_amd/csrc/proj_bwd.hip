@@ -19,6 +19,8 @@ struct DwArgs {
     int64_t ld_dy;
     const float *x;
     int64_t ld_x;
+    const uint8_t *x_mask;  // [N,F] keep mask on X (dropout), or null
+    float x_scale;
     float *partial;  // [n_strips][n_groups][MT*FT][16][64]
     float *dw;       // [M,F]
     int n_strips;
@@ -60,8 +62,11 @@ __global__ __launch_bounds__(256) void k_proj_dw(DwArgs a) {
             for (int mt = 0; mt < MT; ++mt)
                 av[u][mt] = (rok && mok[mt]) ? a.dy[row * a.ld_dy + m0 + mt * 32 + li] : 0.f;
 #pragma unroll
-            for (int ft = 0; ft < FT; ++ft)
-                bv[u][ft] = (rok && fok[ft]) ? a.x[row * a.ld_x + f0 + ft * 32 + li] : 0.f;
+            for (int ft = 0; ft < FT; ++ft) {
+                float b = (rok && fok[ft]) ? a.x[row * a.ld_x + f0 + ft * 32 + li] : 0.f;
+                if (a.x_mask && rok && fok[ft]) b = a.x_mask[row * a.F + f0 + ft * 32 + li] ? b * a.x_scale : 0.f;
+                bv[u][ft] = b;
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -178,7 +183,8 @@ size_t magic_proj_bwd_weight_workspace_bytes(int64_t n_rows, int32_t m, int32_t 
 }
 
 int magic_proj_bwd_weight(int64_t n_rows, int32_t m, int32_t f, const float *dy, int64_t ld_dy, const float *x,
-                          int64_t ld_x, float *dw, void *workspace, size_t workspace_bytes, void *stream_) {
+                          int64_t ld_x, const uint8_t *x_mask, float x_scale, float *dw, void *workspace,
+                          size_t workspace_bytes, void *stream_) {
     if (n_rows < 0 || m <= 0 || f <= 0) return MAGIC_ERR_INVALID_ARG;
     if (!dw) return MAGIC_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)stream_;
@@ -197,6 +203,8 @@ int magic_proj_bwd_weight(int64_t n_rows, int32_t m, int32_t f, const float *dy,
     a.ld_dy = ld_dy;
     a.x = x;
     a.ld_x = ld_x;
+    a.x_mask = x_mask;
+    a.x_scale = x_scale;
     a.partial = ar.take<float>(p.partial_floats);
     if (!ar.ok() || !a.partial) return MAGIC_ERR_WORKSPACE;
     a.dw = dw;

@@ -70,13 +70,13 @@ class _GATLayerFn(torch.autograd.Function):
         out, pre, attn = _lib.gat_fwd(struct, H, Dp, hs, score[:, :H], score[:, H:], table, etype, ee_csc,
                                       cfg["slope"], bias, res, prelu_w, want_pre)
         ctx.struct, ctx.cfg = struct, cfg
-        ctx.save_for_backward(h, w_aug, hs, attn, pre, prelu_w)
+        ctx.save_for_backward(h, w_aug, hs, attn, pre, prelu_w, out if prelu_w is not None else None)
         ctx.mark_non_differentiable(attn)
         return out, attn
 
     @staticmethod
     def backward(ctx, d_out, _d_attn):
-        h, w_aug, hs, attn, pre, prelu_w = ctx.saved_tensors
+        h, w_aug, hs, attn, pre, prelu_w, act_out = ctx.saved_tensors
         struct, cfg = ctx.struct, ctx.cfg
         H, Dp, C, res_c = cfg["H"], cfg["Dp"], cfg["C"], cfg["res_c"]
         N = h.shape[0]
@@ -89,13 +89,13 @@ class _GATLayerFn(torch.autograd.Function):
             d_pre = torch.empty(N, C, dtype=torch.float32, device=h.device)
         etype = cfg["etype_csc"]
         d_table, rec, d_bias, d_prelu = _lib.gat_bwd(
-            struct, H, Dp, hs, attn, etype, cfg["e_dim"], cfg["slope"], pre, prelu_w, d_out, d_pre, d_y,
+            struct, H, Dp, hs, attn, etype, cfg["e_dim"], cfg["slope"], pre, act_out, prelu_w, d_out, d_pre, d_y,
             cfg["has_bias"])
         if res_c and d_pre.data_ptr() != d_y[:, C + 2 * H:].data_ptr():
             d_y[:, C + 2 * H:] = d_pre
         d_h = d_w = d_edge = None
         if ctx.needs_input_grad[0]:
-            d_h = _lib.proj_bwd_input(d_y, w_aug, d_pre if cfg["res_identity"] else None)
+            d_h = _lib.proj_bwd_input(d_y, w_aug, add=d_pre if cfg["res_identity"] else None)[0]
         if ctx.needs_input_grad[1]:
             d_w = _lib.proj_bwd_weight(d_y, h)
         if ctx.needs_input_grad[2]:
@@ -119,7 +119,7 @@ class _LinearNoBiasFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dx = _lib.proj_bwd_input(dy, w) if ctx.needs_input_grad[0] else None
+        dx = _lib.proj_bwd_input(dy, w)[0] if ctx.needs_input_grad[0] else None
         dw = _lib.proj_bwd_weight(dy, x) if ctx.needs_input_grad[1] else None
         return dx, dw
 
