@@ -14,132 +14,41 @@
 // permuted so that lane half (l>>5) owns 16 contiguous k: A and B use the same permutation,
 // which only reorders the k-sum.  All variants are HBM-bound (4N(F+M) bytes against 2NFM
 // flops with F, M <= a few hundred): tiles are sized for streaming, not for reuse.
-#include "common.h"
+#include "proj_common.h"
+
+namespace magic {
+int proj_rows_try(const ProjArgs &a, int64_t *n_part, bool dry_run, hipStream_t stream);
+}
 
 namespace {
 
-typedef float float16_t __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128;     // rows per block (block-tile variant)
-constexpr int KC = 32;      // k per LDS chunk
-constexpr int LDS_LD = 36;  // floats per staged row (144 B)
-
-struct ProjArgs {
-    int64_t n;
-    int F, M, C, NS, RC;
-    const float *x;
-    int64_t ld_x;
-    const uint8_t *x_mask;  // [N,F] keep mask on X (dropout), or null
-    float x_scale;
-    const float *w;
-    int64_t w_rs, w_cs;  // element (row r, k) of the weight = w[r * w_rs + k * w_cs]
-    int col0;            // first output column of this launch (wide outputs take several)
-    const char *name;
-    float *hs;
-    int64_t ld_hs;
-    float *score;
-    float *res;
-    int64_t ld_res;
-    // epilogue chain on the hs columns
-    const float *add;
-    int64_t ld_add;
-    const uint8_t *out_mask;  // [N,C]
-    float out_scale;
-    const float *add2;
-    int64_t ld_add2;
-    const float *act_out;  // forward output of the layer whose PReLU is differentiated
-    int64_t ld_act;
-    const float *act_pre;  // [N,C] its pre-activation (read only when the slope is <= 0)
-    const float *prelu_w;  // device scalar
-    float *part_col;       // [n_part, C] per-wave column sums (or null)
-    float *part_prelu;     // [n_part]
-};
-
-struct Sums {
-    float col;    // running column sum of this lane's column (current column tile)
-    float prelu;  // running slope gradient
-};
-
-// value -> epilogue chain for one element of an hs column; returns the stored value
-__device__ __forceinline__ float chain(const ProjArgs &a, float v, int64_t row, int col, float w, float &dprelu) {
-    if (a.add) v += a.add[row * a.ld_add + col];
-    if (a.out_mask) v = a.out_mask[row * a.C + col] ? v * a.out_scale : 0.f;
-    if (a.add2) v += a.add2[row * a.ld_add2 + col];
-    if (a.act_out) {
-        const float o = a.act_out[row * a.ld_act + col];
-        float pre;
-        if (w > 0.f)
-            pre = o > 0.f ? o : o / w;  // PReLU is invertible for a positive slope
-        else
-            pre = a.act_pre[row * a.C + col];
-        if (!(pre > 0.f)) {
-            dprelu = fmaf(v, pre, dprelu);
-            v *= w;
-        }
-    }
-    return v;
-}
-
-__device__ __forceinline__ float4 load_x4(const ProjArgs &a, int64_t row, int c, bool vec) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < a.n && c < a.F) {
-        const float *p = a.x + row * a.ld_x + c;
-        if (vec && c + 3 < a.F) {
-            v = *reinterpret_cast<const float4 *>(p);
-        } else {
-            v.x = p[0];
-            if (c + 1 < a.F) v.y = p[1];
-            if (c + 2 < a.F) v.z = p[2];
-            if (c + 3 < a.F) v.w = p[3];
-        }
-        if (a.x_mask) {
-            const uint8_t *m = a.x_mask + row * a.F + c;
-            v.x = m[0] ? v.x * a.x_scale : 0.f;
-            if (c + 1 < a.F) v.y = m[1] ? v.y * a.x_scale : 0.f;
-            if (c + 2 < a.F) v.z = m[2] ? v.z * a.x_scale : 0.f;
-            if (c + 3 < a.F) v.w = m[3] ? v.w * a.x_scale : 0.f;
-        }
-    }
-    return v;
-}
-
-__device__ __forceinline__ float4 load_w4(const ProjArgs &a, int r, int c, bool wvec) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.col0 + r < a.M && c < a.F) {
-        const float *p = a.w + (int64_t)(a.col0 + r) * a.w_rs + (int64_t)c * a.w_cs;
-        if (wvec && c + 3 < a.F) {
-            v = *reinterpret_cast<const float4 *>(p);
-        } else {
-            v.x = p[0];
-            if (c + 1 < a.F) v.y = p[a.w_cs];
-            if (c + 2 < a.F) v.z = p[2 * a.w_cs];
-            if (c + 3 < a.F) v.w = p[3 * a.w_cs];
-        }
-    }
-    return v;
-}
-
 // Store one 32x32 accumulator tile (rows t_row0 + map(r, hf), column c_lo + lr) through the
 // epilogue; `csum` collects the column sum of the stored hs values, `dprelu` the slope gradient.
+template <bool EP>
 __device__ __forceinline__ void store_tile(const ProjArgs &a, const float16_t &acc, int64_t row0, int c_lo, int lr,
                                            int hf, float w, float &csum, float &dprelu) {
     const int col = c_lo + lr;
     const bool full_rows = row0 + 32 <= a.n;  // wave-uniform
-    const bool plain = !a.add && !a.out_mask && !a.add2 && !a.act_out && !a.part_col;
+    constexpr bool plain = !EP;
     if (full_rows && c_lo + 32 <= a.C) {  // whole tile in hs
         float *p = a.hs + (row0 + 4 * hf) * a.ld_hs + col;
         if (plain) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * a.ld_hs] = acc[r];
         } else {
-            float v[16];
+            // four rows at a time: keeps the operand loads of one group in flight without
+            // holding all 16 x 4 of them in registers
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                v[r] = chain(a, acc[r], row0 + 4 * hf + (r & 3) + 8 * (r >> 2), col, w, dprelu);
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[((r & 3) + 8 * (r >> 2)) * a.ld_hs] = v[r];
-                csum += v[r];
+                for (int q = 0; q < 4; ++q) v[q] = chain(a, acc[4 * g + q], row0 + 4 * hf + q + 8 * g, col, w, dprelu);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    p[(q + 8 * g) * a.ld_hs] = v[q];
+                    csum += v[q];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         return;
@@ -195,7 +104,7 @@ __device__ __forceinline__ void flush_sums(const ProjArgs &a, const float (&csum
 }
 
 // ---- block-tile variant: 4 waves = 128 rows x all columns, K chunks staged through LDS -------
-template <int NCT>
+template <int NCT, bool EP>
 __global__ __launch_bounds__(256) void k_proj(ProjArgs a) {
     extern __shared__ __align__(16) float sm[];
     float *xs = sm;                // [BM][LDS_LD]
@@ -255,25 +164,41 @@ __global__ __launch_bounds__(256) void k_proj(ProjArgs a) {
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         csum[ct] = 0.f;
-        store_tile(a, acc[ct], row0 + wave * 32, a.col0 + ct * 32, lr, hf, w, csum[ct], dprelu);
+        store_tile<EP>(a, acc[ct], row0 + wave * 32, a.col0 + ct * 32, lr, hf, w, csum[ct], dprelu);
     }
-    flush_sums<NCT>(a, csum, dprelu, lane);
+    if (EP) flush_sums<NCT>(a, csum, dprelu, lane);
 }
 
 // ---- streaming variant: the whole weight block stays in LDS; the four waves are independent,
 // each walks 32-row tiles, copies its tile through a private LDS strip with coalesced 16-byte
 // loads (the next tile's loads are issued before the current tile's MFMAs) and never meets a
 // block barrier after the weight staging.
-template <int NCT, int KCH>
-__global__ __launch_bounds__(256) void k_proj_stream(ProjArgs a) {
+// LDS floats per wave strip: the staged input tile, reused for the transposed output tile
+constexpr int stream_strip(int nct, int kch, int mode) {
+    return 32 * ((mode != 0 && nct * 32 > kch * 32 ? nct * 32 : kch * 32) + 4);
+}
+constexpr size_t stream_lds_c(int nct, int kch, int mode) {
+    return ((size_t)nct * 32 * (kch * 32 + 4) + 4 * (size_t)stream_strip(nct, kch, mode)) * sizeof(float);
+}
+// waves per SIMD the register allocator must leave room for: as many blocks as the LDS footprint allows
+constexpr int stream_waves(int nct, int kch, int mode) { return stream_lds_c(nct, kch, mode) <= 80 * 1024 ? 2 : 1; }
+
+// MODE 0: accumulator tiles stored straight from the MFMA layout, columns routed to hs / score /
+//         res (forward projections).
+// MODE 1: all columns go to hs (M == C, C = NCT*32 ... see dispatch): the tile is transposed through the
+//         wave's LDS strip and stored as whole rows of float4.
+// MODE 2: MODE 1 + the epilogue chain and its column / slope sums.
+template <int NCT, int KCH, int MODE>
+__global__ __launch_bounds__(256, stream_waves(NCT, KCH, MODE)) void k_proj_stream(ProjArgs a) {
     constexpr int KP = KCH * 32;
     constexpr int LDW = KP + 4;  // 16-B aligned rows, 4-bank skew between rows
     constexpr int NV = KP / 8;   // float4 per lane per tile
+    constexpr int STRIP = stream_strip(NCT, KCH, MODE);
     extern __shared__ __align__(16) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hf = lane >> 5, lr = lane & 31;
     float *ws = sm;
-    float *xs = sm + NCT * 32 * LDW + wave * 32 * LDW;
+    float *xs = sm + NCT * 32 * LDW + wave * STRIP;
     const bool wvec = (a.F % 4 == 0) && a.w_cs == 1 && (a.w_rs % 4 == 0) && ((uintptr_t)a.w % 16 == 0);
     for (int idx = tid; idx < NCT * 32 * (KP / 4); idx += 256) {
         const int r = idx / (KP / 4), c4 = (idx % (KP / 4)) * 4;
@@ -284,7 +209,9 @@ __global__ __launch_bounds__(256) void k_proj_stream(ProjArgs a) {
     const int64_t n_tiles = (a.n + 31) / 32;
     const int64_t t_stride = (int64_t)gridDim.x * 4;
     const float w = a.prelu_w ? a.prelu_w[0] : 1.f;
-    float csum[NCT];
+    const float inv_w = w > 0.f ? 1.f / w : 0.f;
+    float csum[NCT];  // MODE 0 only (unused there, kept for store_tile's signature)
+    float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float dprelu = 0.f;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) csum[ct] = 0.f;
@@ -345,11 +272,49 @@ __global__ __launch_bounds__(256) void k_proj_stream(ProjArgs a) {
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc[ct], 0, 0, 0);
             }
         }
+        if (MODE == 0) {
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-            store_tile(a, acc[ct], t * 32, a.col0 + ct * 32, lr, hf, w, csum[ct], dprelu);
+            for (int ct = 0; ct < NCT; ++ct)
+                store_tile<false>(a, acc[ct], t * 32, a.col0 + ct * 32, lr, hf, w, csum[ct], dprelu);
+        } else {
+            // the strip's operands are consumed (LDS operations of a wave complete in order)
+            constexpr int LDO = NCT * 32 + 4;
+            constexpr int C4 = NCT * 8;  // float4 per output row
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    xs[((r & 3) + 8 * (r >> 2) + 4 * hf) * LDO + ct * 32 + lr] = acc[ct][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int i = 0; i < 32 * C4 / 64; ++i) {
+                const int idx = lane + 64 * i;
+                const int r = idx / C4, c4 = (idx % C4) * 4;  // c4 is the same for every i (C4 divides 64)
+                const float4 q = *reinterpret_cast<const float4 *>(xs + r * LDO + c4);
+                epi_store4<MODE == 2>(a, q, t * 32 + r, a.col0 + c4, w, inv_w, cs4, dprelu);
+            }
+        }
     }
-    flush_sums<NCT>(a, csum, dprelu, lane);
+    if (MODE == 2 && a.part_col) {
+        constexpr int C4 = NCT * 8;
+        // lanes l, l + C4, l + 2*C4, ... hold the same four columns
+#pragma unroll
+        for (int off = C4; off < 64; off <<= 1) {
+            cs4.x += __shfl_xor(cs4.x, off, 64);
+            cs4.y += __shfl_xor(cs4.y, off, 64);
+            cs4.z += __shfl_xor(cs4.z, off, 64);
+            cs4.w += __shfl_xor(cs4.w, off, 64);
+        }
+        const int64_t prow = (int64_t)blockIdx.x * 4 + wave;
+        if (lane < C4) *reinterpret_cast<float4 *>(a.part_col + prow * a.C + lane * 4) = cs4;
+        if (a.part_prelu) {
+            float s = dprelu;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (lane == 0) a.part_prelu[prow] = s;
+        }
+    }
 }
 
 // fixed-order reduction of the per-wave partial rows: block c < C sums column c, block C the
@@ -379,10 +344,29 @@ __global__ __launch_bounds__(256) void k_proj_sums(const float *part_col, const 
     }
 }
 
-size_t stream_lds(int nct, int kch) { return (size_t)(nct * 32 + 4 * 32) * (kch * 32 + 4) * sizeof(float); }
+// row-major float4 stores (and epilogue operand loads) are possible
+bool rows_vectorizable(const ProjArgs &a, int nct) {
+    if (a.M != a.C || a.C != nct * 32 || a.col0 != 0) return false;
+    if (nct != 1 && nct != 2 && nct != 4 && nct != 8) return false;
+    if (!aligned16(a.hs, a.ld_hs)) return false;
+    if (a.add && !aligned16(a.add, a.ld_add)) return false;
+    if (a.add2 && !aligned16(a.add2, a.ld_add2)) return false;
+    if (a.act_out && (!aligned16(a.act_out, a.ld_act) || !aligned16(a.act_pre, a.C))) return false;
+    if (a.out_mask && (uintptr_t)a.out_mask % 4 != 0) return false;
+    if (a.part_col && (uintptr_t)a.part_col % 16 != 0) return false;
+    return true;
+}
 
-int stream_grid(const ProjArgs &a, int nct, int kch) {
-    size_t sh = stream_lds(nct, kch);
+size_t stream_lds(int nct, int kch, int mode) { return stream_lds_c(nct, kch, mode); }
+
+int stream_mode(const ProjArgs &a, int nct) {
+    const int kch = (a.F + 31) / 32;
+    if (rows_vectorizable(a, nct) && stream_lds(nct, kch, 2) <= 160 * 1024) return has_epilogue(a) ? 2 : 1;
+    return has_epilogue(a) ? -1 : 0;  // -1: the block-tile kernel carries the element-wise epilogue
+}
+
+int stream_grid(const ProjArgs &a, int nct, int kch, int mode) {
+    size_t sh = stream_lds(nct, kch, mode);
     int64_t tiles = (a.n + 31) / 32;
     int blocks_per_cu = sh <= 40 * 1024 ? 4 : (sh <= 80 * 1024 ? 2 : 1);
     int64_t want = (tiles + 3) / 4;
@@ -390,16 +374,24 @@ int stream_grid(const ProjArgs &a, int nct, int kch) {
     return (int)(want < cap ? want : cap);
 }
 
-template <int NCT, int KCH> int launch_stream(const ProjArgs &a, hipStream_t stream) {
-    size_t sh = stream_lds(NCT, KCH);
+template <int NCT, int KCH, int MODE> int launch_stream_mode(const ProjArgs &a, hipStream_t stream) {
+    size_t sh = stream_lds(NCT, KCH, MODE);
     static bool attr_set = false;
     if (sh > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_proj_stream<NCT, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)sh);
+        (void)hipFuncSetAttribute((const void *)k_proj_stream<NCT, KCH, MODE>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         attr_set = true;
     }
-    MAGIC_LAUNCH(a.name, (k_proj_stream<NCT, KCH>), stream_grid(a, NCT, KCH), 256, sh, stream, a);
+    MAGIC_LAUNCH(a.name, (k_proj_stream<NCT, KCH, MODE>), stream_grid(a, NCT, KCH, MODE), 256, sh, stream, a);
     return magic::launch_status();
+}
+
+template <int NCT, int KCH> int launch_stream(const ProjArgs &a, int mode, hipStream_t stream) {
+    if constexpr ((NCT == 1 || NCT == 2 || NCT == 4 || NCT == 8) && stream_lds_c(NCT, KCH, 2) <= 160 * 1024) {
+        if (mode == 2) return launch_stream_mode<NCT, KCH, 2>(a, stream);
+        if (mode == 1) return launch_stream_mode<NCT, KCH, 1>(a, stream);
+    }
+    return launch_stream_mode<NCT, KCH, 0>(a, stream);
 }
 
 // (column tiles, 32-wide K chunks) pairs with a streaming instantiation
@@ -414,24 +406,31 @@ bool has_stream(int nct, int kch) {
     return false;
 }
 
-template <int NCT> int launch_block(const ProjArgs &a, hipStream_t stream) {
+template <int NCT, bool EP> int launch_block_ep(const ProjArgs &a, hipStream_t stream) {
     size_t sh = (size_t)(BM + NCT * 32) * LDS_LD * sizeof(float);
     unsigned grid = (unsigned)((a.n + BM - 1) / BM);
     static bool attr_set = false;
     if (sh > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_proj<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute((const void *)k_proj<NCT, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         attr_set = true;
     }
-    MAGIC_LAUNCH(a.name, (k_proj<NCT>), grid, 256, sh, stream, a);
+    MAGIC_LAUNCH(a.name, (k_proj<NCT, EP>), grid, 256, sh, stream, a);
     return magic::launch_status();
+}
+
+template <int NCT> int launch_block(const ProjArgs &a, hipStream_t stream) {
+    return has_epilogue(a) ? launch_block_ep<NCT, true>(a, stream) : launch_block_ep<NCT, false>(a, stream);
 }
 
 int dispatch_one(const ProjArgs &a, int nct, hipStream_t stream) {
     const int kch = (a.F + 31) / 32;
+    const int mode = stream_mode(a, nct);
+    if (mode >= 0) {
 #define X(n, k) \
-    if (nct == n && kch == k) return launch_stream<n, k>(a, stream);
-    MAGIC_PROJ_STREAM_SHAPES(X)
+    if (nct == n && kch == k) return launch_stream<n, k>(a, mode, stream);
+        MAGIC_PROJ_STREAM_SHAPES(X)
 #undef X
+    }
     switch (nct) {
         case 1: return launch_block<1>(a, stream);
         case 2: return launch_block<2>(a, stream);
@@ -450,13 +449,17 @@ int dispatch_one(const ProjArgs &a, int nct, hipStream_t stream) {
 // number of partial rows (= waves of the grid) one launch over `nct` column tiles writes
 int64_t n_partials(const ProjArgs &a, int nct) {
     const int kch = (a.F + 31) / 32;
-    if (has_stream(nct, kch)) return (int64_t)stream_grid(a, nct, kch) * 4;
+    const int mode = stream_mode(a, nct);
+    if (mode >= 0 && has_stream(nct, kch)) return (int64_t)stream_grid(a, nct, kch, mode) * 4;
     return ((a.n + BM - 1) / BM) * 4;
 }
 
 // up to 10 column tiles (320 outputs) per launch; wider outputs take several launches of 8
 int dispatch(const ProjArgs &a0, hipStream_t stream) {
     ProjArgs a = a0;
+    a.col0 = 0;
+    const int st_rows = magic::proj_rows_try(a, nullptr, false, stream);
+    if (st_rows != MAGIC_ERR_UNSUPPORTED) return st_rows;
     const int tiles = (a.M + 31) / 32;
     if (tiles <= 10) {
         a.col0 = 0;
@@ -530,13 +533,9 @@ int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_scor
 
 size_t magic_proj_bwd_input_workspace_bytes(int64_t n_rows, int32_t k_dim, int32_t out_dim) {
     if (n_rows <= 0 || k_dim <= 0 || out_dim <= 0) return 256;
-    ProjArgs a;
-    init_args(a);
-    a.n = n_rows;
-    a.F = k_dim;
-    a.M = a.C = out_dim;
-    const int tiles = (out_dim + 31) / 32;
-    int64_t np = tiles <= 10 ? n_partials(a, tiles) : n_partials(a, 8);
+    // upper bound over the kernel variants: one partial row per wave of the grid
+    int64_t np = ((n_rows + BM - 1) / BM) * 4;
+    if (np < 4096) np = 4096;
     return magic::align_up((size_t)np * out_dim * sizeof(float)) + magic::align_up((size_t)np * sizeof(float)) + 256;
 }
 
@@ -580,7 +579,8 @@ int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim, const f
     if (sums) {
         const int tiles = (out_dim + 31) / 32;
         if (tiles > 10) return MAGIC_ERR_UNSUPPORTED;  // column sums need a single launch
-        np = n_partials(a, tiles);
+        a.part_col = static_cast<float *>(workspace);  // provisional: the kernel choice looks at it
+        if (magic::proj_rows_try(a, &np, true, stream) != MAGIC_OK) np = n_partials(a, tiles);
         magic::Arena ar(workspace, workspace_bytes);
         a.part_col = ar.take<float>((size_t)np * out_dim);
         a.part_prelu = ar.take<float>((size_t)np);

@@ -46,25 +46,50 @@ __global__ __launch_bounds__(256) void k_proj_dw(DwArgs a) {
     const int64_t r_beg = ((int64_t)strip * 4 + wave) * a.rows_per_wave;
     int64_t r_end = r_beg + a.rows_per_wave;
     if (r_end > a.n) r_end = a.n;
+    // Loads are unconditional (clamped addresses, values zeroed afterwards): no divergent control
+    // flow around them, so one iteration's U*(MT+FT) loads are all in flight together.
     bool mok[MT], fok[FT];
+    int mcol[MT], fcol[FT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) mok[mt] = m0 + mt * 32 + li < a.M;
+    for (int mt = 0; mt < MT; ++mt) {
+        mok[mt] = m0 + mt * 32 + li < a.M;
+        mcol[mt] = mok[mt] ? m0 + mt * 32 + li : 0;
+    }
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft) fok[ft] = f0 + ft * 32 + li < a.F;
-    constexpr int U = 4;  // k-steps in flight
+    for (int ft = 0; ft < FT; ++ft) {
+        fok[ft] = f0 + ft * 32 + li < a.F;
+        fcol[ft] = fok[ft] ? f0 + ft * 32 + li : 0;
+    }
+#ifndef MAGIC_DW_U
+#define MAGIC_DW_U 8
+#endif
+    constexpr int U = MAGIC_DW_U;  // k-steps in flight
+    const int64_t last = a.n - 1;
     for (int64_t r = r_beg; r < r_end; r += 2 * U) {
         float av[U][MT], bv[U][FT];
+        uint8_t mv[U][FT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t row = r + 2 * u + hf;
-            const bool rok = row < r_end;
+            const int64_t rc = row < last ? row : last;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                av[u][mt] = (rok && mok[mt]) ? a.dy[row * a.ld_dy + m0 + mt * 32 + li] : 0.f;
+            for (int mt = 0; mt < MT; ++mt) av[u][mt] = a.dy[rc * a.ld_dy + mcol[mt]];
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) bv[u][ft] = a.x[rc * a.ld_x + fcol[ft]];
+            if (a.x_mask) {
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft) mv[u][ft] = a.x_mask[rc * a.F + fcol[ft]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool rok = r + 2 * u + hf < r_end;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[u][mt] = (rok && mok[mt]) ? av[u][mt] : 0.f;
 #pragma unroll
             for (int ft = 0; ft < FT; ++ft) {
-                float b = (rok && fok[ft]) ? a.x[row * a.ld_x + f0 + ft * 32 + li] : 0.f;
-                if (a.x_mask && rok && fok[ft]) b = a.x_mask[row * a.F + f0 + ft * 32 + li] ? b * a.x_scale : 0.f;
+                float b = (rok && fok[ft]) ? bv[u][ft] : 0.f;
+                if (a.x_mask) b = mv[u][ft] ? b * a.x_scale : 0.f;
                 bv[u][ft] = b;
             }
         }
@@ -145,11 +170,11 @@ DwPlan plan_dw(int64_t n, int M, int F) {
     p.mg = (mtiles + p.mt - 1) / p.mt;
     p.fg = (ftiles + p.ft - 1) / p.ft;
     int groups = p.mg * p.fg;
-    int strips = 1024 / groups;  // ~4 blocks per CU in flight
+    int strips = 512 / groups;  // two resident blocks per CU: the whole grid runs as one wave of blocks
     if (strips < 8) strips = 8;
     int64_t waves = (int64_t)strips * 4;
     int64_t rpw = (n + waves - 1) / waves;
-    rpw = (rpw + 7) / 8 * 8;  // whole unrolled iterations
+    rpw = (rpw + 2 * MAGIC_DW_U - 1) / (2 * MAGIC_DW_U) * (2 * MAGIC_DW_U);  // whole unrolled iterations
     if (rpw < 8) rpw = 8;
     p.rows_per_wave = rpw;
     p.n_strips = (int)((n + rpw * 4 - 1) / (rpw * 4));

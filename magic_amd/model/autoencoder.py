@@ -23,7 +23,8 @@ import torch.nn as nn
 
 from ..graph import Graph
 from ..utils.utils import create_norm
-from .gat import GAT, linear_nobias
+from .fused import FusedCfg, FusedGMAEFn
+from .gat import GAT, _pad_head_dim, linear_nobias
 from .loss_func import sce_loss, sce_loss_masked
 
 
@@ -124,24 +125,58 @@ class GMAEModel(nn.Module):
     def forward(self, g, **overrides):
         return self.compute_loss(g, **overrides)
 
-    def compute_loss(self, g: Graph, perm=None, pos_idx=None, neg_pairs=None, return_parts=False):
-        """``model/autoencoder.py:218-267``."""
+    def _dropout_masks(self, widths, n, device, drop_masks):
+        """One uint8 keep mask per GAT layer input (``model/gat.py:283``), or Nones when dropout
+        is inactive.  ``drop_masks`` (0/1 tensors, any dtype) replaces the Bernoulli draws."""
+        p = self.encoder.gats[0].feat_drop.p
+        if drop_masks is not None:
+            assert len(drop_masks) == len(widths)
+            return [m.to(device=device, dtype=torch.uint8).contiguous() for m in drop_masks], 1.0 / (1.0 - p)
+        if not self.training or p == 0.0:
+            return [None] * len(widths), 1.0
+        return [torch.empty(n, w, dtype=torch.uint8, device=device).bernoulli_(1.0 - p) for w in widths], \
+            1.0 / (1.0 - p)
+
+    def _fused_cfg(self, g: Graph, drop_masks):
+        """Description of the whole encoder -> decoder chain for ``FusedGMAEFn``, or None when a
+        layer needs the generic per-layer path (norm layers, non-PReLU activations, head widths
+        that need padding inside the encoder, dense edge attributes ...)."""
+        enc, dec = self.encoder.gats, self.decoder.gats
+        etype = g.edge_types_csc()
+        if etype is None or len(dec) != 1 or not torch.is_grad_enabled():
+            return None
+        H, D = enc[0].n_heads, enc[0].out_feat
+        if _pad_head_dim(D) != D or (2 * H) % 4 != 0:
+            return None
+        p = enc[0].feat_drop.p
+        res_kinds = []
+        for i, layer in enumerate(enc):
+            ok = (layer.n_heads == H and layer.out_feat == D and layer.norm is None and layer.concat_out
+                  and isinstance(layer.activation, nn.PReLU) and layer.activation.weight.numel() == 1
+                  and layer.bias is not None and layer.attn_drop.p == 0.0 and layer.feat_drop.p == p
+                  and (i == 0 or layer.src_feat == H * D))
+            if not ok:
+                return None
+            res_kinds.append("linear" if isinstance(layer.res_fc, nn.Linear)
+                             else "identity" if isinstance(layer.res_fc, nn.Identity) else None)
+        d = dec[0]
+        if not (d.n_heads == 1 and d.norm is None and d.activation is None and d.res_fc is None
+                and d.bias is not None and d.concat_out and d.attn_drop.p == 0.0 and d.feat_drop.p == p):
+            return None
+        n = g.num_nodes()
+        widths = [enc[0].src_feat] + [H * D] * (len(enc) - 1) + [d.src_feat]
+        masks, scale = self._dropout_masks(widths, n, g.device, drop_masks)
+        return FusedCfg(g.structure.ensure_csr(), etype, enc[0].edge_feat, len(enc), H, D, d.out_feat,
+                        _pad_head_dim(d.out_feat), enc[0].leaky_relu.negative_slope, res_kinds, masks, scale)
+
+    def compute_loss(self, g: Graph, perm=None, pos_idx=None, neg_pairs=None, drop_masks=None, return_parts=False,
+                     fused=True):
+        """``model/autoencoder.py:218-267``.  ``fused=False`` forces the layer-by-layer path."""
         pre_use_g, (mask_nodes, keep_nodes) = self.encoding_mask_noise(g, self._mask_rate, perm)
         pre_use_x = pre_use_g.ndata["attr"].to(pre_use_g.device)
         use_g = pre_use_g
-        enc_rep, all_hidden = self.encoder(use_g, pre_use_x, return_hidden=True)
-        enc_rep = torch.cat(all_hidden, dim=1)
-        rep = linear_nobias(enc_rep, self.encoder_to_decoder.weight)   # autoencoder.py:237
-        recon = self.decoder(pre_use_g, rep)
-        # autoencoder.py:242-245: gather of the masked rows fused into the loss kernel
-        x_target = g.ndata["attr"]
-        if x_target.data_ptr() == pre_use_x.data_ptr():
-            # shared storage: every masked row of the target IS the mask token
-            loss_sce = sce_loss_masked(recon, self.enc_mask_token, mask_nodes, self._alpha_l)
-        else:
-            loss_sce = sce_loss_masked(recon, x_target, mask_nodes, self._alpha_l)
-        loss = loss_sce
-        # autoencoder.py:248-266: sampled edge reconstruction
+        # autoencoder.py:248-256: node pairs of the sampled edge reconstruction (drawn first: the
+        # fused chain gathers their hidden rows itself)
         threshold = min(10000, g.num_nodes())
         if neg_pairs is None:
             neg_pairs = global_uniform_negative_sampling(g, threshold)
@@ -151,9 +186,37 @@ class GMAEModel(nn.Module):
         src, dst = g.edges()
         pos = (src[pos_idx], dst[pos_idx])
         neg = (neg_pairs[0].to(g.device), neg_pairs[1].to(g.device))
-        sample_src = enc_rep[torch.cat([pos[0], neg[0]])]
-        sample_dst = enc_rep[torch.cat([pos[1], neg[1]])]
-        y_pred = self.edge_recon_fc(torch.cat([sample_src, sample_dst], dim=-1)).squeeze(-1)
+        n_pairs = len(pos[0]) + len(neg[0])
+        sample_idx = torch.cat([pos[0], neg[0], pos[1], neg[1]])
+
+        cfg = self._fused_cfg(use_g, drop_masks) if fused else None
+        if cfg is not None:
+            params = []
+            for layer in self.encoder.gats:
+                params += list(layer.fused_params(cfg.D))
+            params.append(self.encoder_to_decoder.weight)
+            params += list(self.decoder.gats[0].fused_params(cfg.Dp))[:3]
+            enc_rep, recon, samples = FusedGMAEFn.apply(pre_use_x, sample_idx, cfg, *params)
+            recon = recon[:, :cfg.n_dim]
+            all_hidden = [enc_rep[:, i * cfg.C:(i + 1) * cfg.C] for i in range(cfg.L)]
+        else:
+            if drop_masks is not None:
+                raise NotImplementedError("injected dropout masks need the fused chain")
+            enc_rep, all_hidden = self.encoder(use_g, pre_use_x, return_hidden=True)
+            enc_rep = torch.cat(all_hidden, dim=1)
+            rep = linear_nobias(enc_rep, self.encoder_to_decoder.weight)   # autoencoder.py:237
+            recon = self.decoder(pre_use_g, rep)
+            samples = enc_rep[sample_idx]
+        # autoencoder.py:242-245: gather of the masked rows fused into the loss kernel
+        x_target = g.ndata["attr"]
+        if x_target.data_ptr() == pre_use_x.data_ptr():
+            # shared storage: every masked row of the target IS the mask token
+            loss_sce = sce_loss_masked(recon, self.enc_mask_token, mask_nodes, self._alpha_l)
+        else:
+            loss_sce = sce_loss_masked(recon, x_target, mask_nodes, self._alpha_l)
+        loss = loss_sce
+        # autoencoder.py:257-266: sampled edge reconstruction
+        y_pred = self.edge_recon_fc(torch.cat([samples[:n_pairs], samples[n_pairs:]], dim=-1)).squeeze(-1)
         y = torch.cat([torch.ones(len(pos[0]), device=g.device), torch.zeros(len(neg[0]), device=g.device)])
         loss_bce = self.recon_loss(y_pred, y)
         loss = loss + loss_bce

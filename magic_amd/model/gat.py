@@ -209,6 +209,23 @@ class GATConv(nn.Module):
             parts.append(rw)
         return torch.cat(parts, 0)
 
+    def _padded_bias(self, Dp: int):
+        if self.bias is None:
+            return None
+        H, D = self.n_heads, self.out_feat
+        bias = self.bias.view(H, D)
+        if Dp != D:
+            bias = torch.cat([bias, bias.new_zeros(H, Dp - D)], 1)
+        return bias.reshape(-1)
+
+    def fused_params(self, Dp: int):
+        """(augmented weight, [e_dim, H] edge score table, flat bias, PReLU slope | None): the
+        differentiable operands the whole-network node in ``fused.py`` consumes."""
+        H, D = self.n_heads, self.out_feat
+        table = _fold(self.edge_fc.weight, self.attn_e, H, D).t()      # gat.py:297-299 collapsed
+        prelu_w = self.activation.weight if isinstance(self.activation, nn.PReLU) else None
+        return self._augmented_weight(Dp), table, self._padded_bias(Dp), prelu_w
+
     def forward(self, graph: Graph, feat, get_attention=False):
         if isinstance(feat, tuple):
             raise NotImplementedError("bipartite (src, dst) inputs are not used by MAGIC and have no HIP kernel")
@@ -236,12 +253,7 @@ class GATConv(nn.Module):
         fuse_act = isinstance(self.activation, nn.PReLU) and self.activation.weight.numel() == 1 \
             and self.norm is None and self.concat_out
         prelu_w = self.activation.weight if fuse_act else None
-        bias = None
-        if self.bias is not None:
-            bias = self.bias.view(H, D)
-            if Dp != D:
-                bias = torch.cat([bias, bias.new_zeros(H, Dp - D)], 1)
-            bias = bias.reshape(-1)
+        bias = self._padded_bias(Dp)
         need_grad = torch.is_grad_enabled()
         cfg = dict(H=H, Dp=Dp, C=C, res_c=C if isinstance(self.res_fc, nn.Linear) else 0,
                    res_identity=res_identity, etype_csc=etype_csc, e_dim=self.edge_feat,

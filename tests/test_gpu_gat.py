@@ -113,23 +113,47 @@ def _model_pair(n_dim, e_dim, hidden, layers, dev, seed=0, alias=True):
     return ref, mine.to(dev)
 
 
-@pytest.mark.parametrize("shape,alias", [((5, 17, 64, 3), True), ((5, 17, 64, 3), False), ((8, 20, 256, 4), True)])
-def test_autoencoder_loss_and_grads(cuda, shape, alias):
+@pytest.mark.parametrize("shape,alias,mode", [
+    ((5, 17, 64, 3), True, "eval"), ((5, 17, 64, 3), False, "eval"), ((8, 20, 256, 4), True, "eval"),
+    ((5, 17, 64, 3), True, "perlayer"),      # layer-by-layer autograd path
+    ((5, 17, 64, 3), True, "drop"),          # training mode, dropout masks injected on both sides
+    ((12, 9, 128, 2), False, "drop"),
+    ((5, 17, 64, 3), True, "negslope"),      # PReLU slopes <= 0: pre-activation must come from storage
+    ((6, 7, 32, 2), True, "drop"),
+])
+def test_autoencoder_loss_and_grads(cuda, shape, alias, mode):
     n_dim, e_dim, hidden, layers = shape
     n, e = 700, 3000
     src, dst, ntype, etype = small_graph(n, e, n_dim, e_dim, seed=21, hub_deg=200, hub_out=150)
     ref, mine = _model_pair(n_dim, e_dim, hidden, layers, cuda, alias=alias)
-    ref.eval()
-    mine.eval()   # dropout off on both sides; everything else is the training graph
     gen = torch.Generator().manual_seed(5)
+    drop_o = drop_m = None
+    if mode == "drop":
+        ref.train()
+        mine.train()
+        widths = [n_dim] + [hidden] * (layers - 1) + [hidden]
+        keep = [(torch.rand(n, w, generator=gen) < 0.9) for w in widths]
+        drop_o = [k.double() for k in keep]
+        drop_m = [k.to(cuda) for k in keep]
+    else:
+        ref.eval()
+        mine.eval()   # dropout off on both sides; everything else is the training graph
+    if mode == "negslope":
+        with torch.no_grad():
+            for i, (lo_, lm_) in enumerate(zip(ref.encoder.gats, mine.encoder.gats)):
+                v = (-0.3, 0.0, 0.25)[i % 3]
+                lo_.activation.weight.fill_(v)
+                lm_.activation.weight.fill_(v)
     perm = torch.randperm(n, generator=gen)
     pos_idx = torch.randperm(src.size, generator=gen)[:n]
     og64 = to_ograph(src, dst, n, ntype, etype, n_dim, e_dim, torch.float64)
     neg = O.uniform_negative_pairs(og64, n, seed=9)
     ref64 = copy.deepcopy(ref).double()
-    lo, parts_o = ref64.compute_loss(og64, perm=perm, pos_idx=pos_idx, neg_pairs=neg, return_parts=True)
+    lo, parts_o = ref64.compute_loss(og64, perm=perm, pos_idx=pos_idx, neg_pairs=neg, drop_masks=drop_o,
+                                     return_parts=True)
     g = to_graph(src, dst, n, ntype, etype, n_dim, e_dim, cuda)
-    lm, parts_m = mine.compute_loss(g, perm=perm.to(cuda), pos_idx=pos_idx, neg_pairs=neg, return_parts=True)
+    lm, parts_m = mine.compute_loss(g, perm=perm.to(cuda), pos_idx=pos_idx, neg_pairs=neg, drop_masks=drop_m,
+                                    return_parts=True, fused=mode != "perlayer")
     assert abs(float(lm) - float(lo)) / abs(float(lo)) < 1e-4
     assert abs(float(parts_m["sce"]) - float(parts_o["sce"])) / abs(float(parts_o["sce"])) < 1e-4
     for hm, ho in zip(parts_m["hidden"], parts_o["hidden"]):
@@ -142,6 +166,35 @@ def test_autoencoder_loss_and_grads(cuda, shape, alias):
             continue
         assert pm.grad is not None, k
         assert rel_err(pm.grad, po.grad) < 5e-4, k
+
+
+def test_fused_chain_matches_layer_path_and_is_reproducible(cuda):
+    """Same arithmetic in both paths: results agree to rounding, and the fused chain is bitwise
+    reproducible run to run (fixed-order reductions, no atomics)."""
+    n_dim, e_dim, hidden, layers = 9, 13, 64, 3
+    n, e = 1500, 9000
+    src, dst, ntype, etype = small_graph(n, e, n_dim, e_dim, seed=4, hub_deg=500, hub_out=300)
+    _, mine = _model_pair(n_dim, e_dim, hidden, layers, cuda)
+    mine.eval()
+    gen = torch.Generator().manual_seed(1)
+    perm = torch.randperm(n, generator=gen).to(cuda)
+    pos_idx = torch.randperm(src.size, generator=gen)[:n]
+    neg = (torch.randint(0, n, (n,), generator=gen), torch.randint(0, n, (n,), generator=gen))
+    outs = []
+    for fused in (True, True, False):
+        # a fresh graph per pass: the token write of the masking step lands in the graph's own
+        # feature tensor (shared storage), which then carries autograd history
+        g = to_graph(src, dst, n, ntype, etype, n_dim, e_dim, cuda)
+        mine.zero_grad(set_to_none=True)
+        loss = mine.compute_loss(g, perm=perm, pos_idx=pos_idx, neg_pairs=neg, fused=fused)
+        loss.backward()
+        outs.append((loss.detach().clone(), [p.grad.clone() for p in mine.parameters() if p.grad is not None]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    assert abs(float(outs[0][0]) - float(outs[2][0])) < 1e-5 * abs(float(outs[2][0]))
+    for a, b in zip(outs[0][1], outs[2][1]):
+        assert rel_err(a, b) < 1e-4
 
 
 def test_embed_matches_oracle_and_is_deterministic(cuda):
