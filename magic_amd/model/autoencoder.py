@@ -24,7 +24,7 @@ import torch.nn as nn
 from ..graph import Graph
 from ..utils.utils import create_norm
 from .fused import FusedCfg, FusedGMAEFn
-from .gat import GAT, _pad_head_dim, linear_nobias
+from .gat import GAT, _LinearFn, _pad_head_dim, linear_nobias
 from .loss_func import sce_loss, sce_loss_masked
 
 
@@ -169,9 +169,18 @@ class GMAEModel(nn.Module):
         return FusedCfg(g.structure.ensure_csr(), etype, enc[0].edge_feat, len(enc), H, D, d.out_feat,
                         _pad_head_dim(d.out_feat), enc[0].leaky_relu.negative_slope, res_kinds, masks, scale)
 
+    def _edge_recon(self, pairs):
+        """``edge_recon_fc`` (``model/autoencoder.py:75-78``) with the weight gradients of its two
+        linear layers on the streaming dW kernel (a [rows, features] reduction over ~20k rows that
+        the BLAS heuristics serve badly); everything else stays torch."""
+        fc1, act, fc2, sig = self.edge_recon_fc
+        h = act(_LinearFn.apply(pairs, fc1.weight, fc1.bias))
+        return sig(_LinearFn.apply(h, fc2.weight, fc2.bias))
+
     def compute_loss(self, g: Graph, perm=None, pos_idx=None, neg_pairs=None, drop_masks=None, return_parts=False,
                      fused=True):
         """``model/autoencoder.py:218-267``.  ``fused=False`` forces the layer-by-layer path."""
+        feat_has_grad = g.ndata["attr"].requires_grad
         pre_use_g, (mask_nodes, keep_nodes) = self.encoding_mask_noise(g, self._mask_rate, perm)
         pre_use_x = pre_use_g.ndata["attr"].to(pre_use_g.device)
         use_g = pre_use_g
@@ -196,8 +205,15 @@ class GMAEModel(nn.Module):
                 params += list(layer.fused_params(cfg.D))
             params.append(self.encoder_to_decoder.weight)
             params += list(self.decoder.gats[0].fused_params(cfg.Dp))[:3]
-            enc_rep, recon, samples = FusedGMAEFn.apply(pre_use_x, sample_idx, cfg, *params)
-            recon = recon[:, :cfg.n_dim]
+            if feat_has_grad:
+                enc_rep, recon_p, samples = FusedGMAEFn.apply(pre_use_x, sample_idx, cfg, None, *params)
+            else:
+                # the features' only differentiable content is the token written into the masked
+                # rows: hand the chain the plain values and let it return the token's gradient
+                cfg.token_rows = mask_nodes
+                enc_rep, recon_p, samples = FusedGMAEFn.apply(pre_use_x.detach(), sample_idx, cfg,
+                                                              self.enc_mask_token, *params)
+            recon = recon_p[:, :cfg.n_dim]
             all_hidden = [enc_rep[:, i * cfg.C:(i + 1) * cfg.C] for i in range(cfg.L)]
         else:
             if drop_masks is not None:
@@ -205,18 +221,21 @@ class GMAEModel(nn.Module):
             enc_rep, all_hidden = self.encoder(use_g, pre_use_x, return_hidden=True)
             enc_rep = torch.cat(all_hidden, dim=1)
             rep = linear_nobias(enc_rep, self.encoder_to_decoder.weight)   # autoencoder.py:237
-            recon = self.decoder(pre_use_g, rep)
+            recon = recon_p = self.decoder(pre_use_g, rep)
             samples = enc_rep[sample_idx]
         # autoencoder.py:242-245: gather of the masked rows fused into the loss kernel
         x_target = g.ndata["attr"]
+        # (the loss kernel takes the head-padded reconstruction as it is and leaves zeros in the
+        # padding columns of its gradient)
+        n_dim = recon.shape[1]
         if x_target.data_ptr() == pre_use_x.data_ptr():
             # shared storage: every masked row of the target IS the mask token
-            loss_sce = sce_loss_masked(recon, self.enc_mask_token, mask_nodes, self._alpha_l)
+            loss_sce = sce_loss_masked(recon_p, self.enc_mask_token, mask_nodes, self._alpha_l, n_dim=n_dim)
         else:
-            loss_sce = sce_loss_masked(recon, x_target, mask_nodes, self._alpha_l)
+            loss_sce = sce_loss_masked(recon_p, x_target, mask_nodes, self._alpha_l, n_dim=n_dim)
         loss = loss_sce
         # autoencoder.py:257-266: sampled edge reconstruction
-        y_pred = self.edge_recon_fc(torch.cat([samples[:n_pairs], samples[n_pairs:]], dim=-1)).squeeze(-1)
+        y_pred = self._edge_recon(torch.cat([samples[:n_pairs], samples[n_pairs:]], dim=-1)).squeeze(-1)
         y = torch.cat([torch.ones(len(pos[0]), device=g.device), torch.zeros(len(neg[0]), device=g.device)])
         loss_bce = self.recon_loss(y_pred, y)
         loss = loss + loss_bce

@@ -33,7 +33,7 @@ class FusedCfg:
     """Static description of one auto-encoder evaluation (built per call by GMAEModel)."""
 
     def __init__(self, struct, etype_csc, e_dim, n_layers, n_heads, head_dim, n_dim, dec_dim_pad, slope, res_kinds,
-                 masks: List[Optional[torch.Tensor]], drop_scale: float):
+                 masks: List[Optional[torch.Tensor]], drop_scale: float, token_rows: Optional[torch.Tensor] = None):
         self.struct, self.etype, self.e_dim = struct, etype_csc, e_dim
         self.L, self.H, self.D, self.C = n_layers, n_heads, head_dim, n_heads * head_dim
         self.n_dim, self.Dp = n_dim, dec_dim_pad
@@ -41,6 +41,9 @@ class FusedCfg:
         self.res_kinds = res_kinds          # per encoder layer: "linear" | "identity" | None
         self.masks = masks                  # L encoder masks + 1 decoder mask (uint8 [N,F] or None)
         self.scale = drop_scale
+        # rows of x that hold the (learnable) mask token: with them given, the token's gradient is
+        # produced directly and the input gradient is never materialised
+        self.token_rows = token_rows
 
 
 def _aligned_rows(n, cols, device):
@@ -50,12 +53,13 @@ def _aligned_rows(n, cols, device):
 
 
 class FusedGMAEFn(torch.autograd.Function):
-    """inputs: x [N,n_dim], sample_idx [S] (rows of the hidden buffer to gather), cfg, then per
+    """inputs: x [N,n_dim], sample_idx [S] (rows of the hidden buffer to gather), cfg, the mask
+    token [1,n_dim] (or None; only its gradient is produced here, x already contains it), then per
     encoder layer (w_aug, table, bias, prelu_w), then w_e2d, then decoder (w_aug, table, bias).
     outputs: hidden [N, L*C] (not differentiable from outside), recon [N, Dp], samples [S, L*C]."""
 
     @staticmethod
-    def forward(ctx, x, sample_idx, cfg: FusedCfg, *params):
+    def forward(ctx, x, sample_idx, cfg: FusedCfg, token, *params):
         L, H, D, C = cfg.L, cfg.H, cfg.D, cfg.C
         s = cfg.struct
         N = x.shape[0]
@@ -130,7 +134,7 @@ class FusedGMAEFn(torch.autograd.Function):
         # ---- encoder layers, last to first.  State handed from layer l+1 to layer l: the finished
         # pre-activation gradient d_pre of layer l, the d_y buffer it may live in, and the bias /
         # PReLU-slope gradients that came out of the same epilogue.
-        d_x = None
+        d_x = d_token = None
         d_pre = d_y_next = bias_grad = prelu_grad = None
         off = C + 2 * H
         for l in range(L - 1, -1, -1):
@@ -151,7 +155,10 @@ class FusedGMAEFn(torch.autograd.Function):
                 d_y = d_y_next if d_y_next is not None else _aligned_rows(N, w_aug.shape[0], dev)
                 d_table = _lib.gat_bwd(s, H, D, hs, attn, cfg.etype, cfg.e_dim, cfg.slope, None, None, None,
                                        d_pre, d_pre, d_y, False)[0]
-            grads[4 * l] = _lib.proj_bwd_weight(d_y, inp, x_mask=mask, x_scale=cfg.scale)
+            token_path = (l == 0 and cfg.token_rows is not None and ctx.needs_input_grad[3]
+                          and not ctx.needs_input_grad[0] and kind != "identity")
+            if not token_path:  # (the token path below produces this layer's weight gradient itself)
+                grads[4 * l] = _lib.proj_bwd_weight(d_y, inp, x_mask=mask, x_scale=cfg.scale)
             grads[4 * l + 1] = d_table
             grads[4 * l + 2] = bias_grad
             grads[4 * l + 3] = prelu_grad.view_as(prelu_w)
@@ -166,8 +173,26 @@ class FusedGMAEFn(torch.autograd.Function):
                     d_y, w_aug, add=add, out_mask=mask, out_scale=cfg.scale, add2=d_enc[:, (l - 1) * C:l * C],
                     act_out=inp, act_pre=saved[3 * (l - 1) + 2], prelu_w=params[4 * (l - 1) + 3],
                     want_col_sum=True, out=target)
-            elif ctx.needs_input_grad[0]:
-                d_x = _lib.proj_bwd_input(d_y, w_aug, add=add)[0]
-                if mask is not None:  # [N, n_dim] is narrow: not worth an epilogue variant
-                    d_x = d_x * mask * cfg.scale
-        return (d_x, None, None, *grads)
+            else:
+                want_token = cfg.token_rows is not None and ctx.needs_input_grad[3]
+                if want_token and not ctx.needs_input_grad[0] and add is None:
+                    # d_token[c] = sum over token rows of d_x[:, c] without forming d_x: append the
+                    # row indicator (broadcast over the n_dim columns, same dropout mask) to the
+                    # weight-gradient operand, G = d_y^T (ind * mask); d_token = colsum(G * W)
+                    F0 = inp.shape[1]
+                    ind = torch.zeros(N, 1, dtype=torch.float32, device=dev)
+                    ind.index_fill_(0, cfg.token_rows, 1.0)
+                    x2 = torch.cat([inp, ind.expand(N, F0)], 1)
+                    m2 = torch.cat([mask, mask], 1) if mask is not None else None
+                    dw2 = _lib.proj_bwd_weight(d_y, x2, x_mask=m2, x_scale=cfg.scale)
+                    grads[0] = dw2[:, :F0]
+                    d_token = (dw2[:, F0:] * w_aug).sum(0, keepdim=True)
+                elif ctx.needs_input_grad[0] or want_token:
+                    d_x = _lib.proj_bwd_input(d_y, w_aug, add=add)[0]
+                    if mask is not None:  # [N, n_dim] is narrow: not worth an epilogue variant
+                        d_x = d_x * mask * cfg.scale
+                    if want_token:
+                        d_token = d_x[cfg.token_rows].sum(0, keepdim=True)
+                    if not ctx.needs_input_grad[0]:
+                        d_x = None
+        return (d_x, None, None, d_token, *grads)

@@ -124,6 +124,25 @@ class _LinearNoBiasFn(torch.autograd.Function):
         return dx, dw
 
 
+class _LinearFn(torch.autograd.Function):
+    """``F.linear(x, w, b)`` whose weight gradient (a reduction over the rows of x) runs on the
+    streaming dW kernel; forward and input gradient stay on the BLAS."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dw = _lib.proj_bwd_weight(dy, x) if ctx.needs_input_grad[1] else None
+        db = dy.sum(0) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
 def linear_nobias(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """``torch.nn.functional.linear(x, w)`` for GPU tensors with up to 320 output features."""
     return _LinearNoBiasFn.apply(x, w)

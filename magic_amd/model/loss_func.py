@@ -12,13 +12,13 @@ class _SCEMaskedFn(torch.autograd.Function):
     the target of masked row i) or a single ``[1, n]`` row shared by all masked rows."""
 
     @staticmethod
-    def forward(ctx, x, target, mask_idx, alpha):
+    def forward(ctx, x, target, mask_idx, alpha, n_dim):
         single = target.dim() == 2 and target.shape[0] == 1 and x.shape[0] != 1
         if x.stride(-1) != 1:
             x = x.contiguous()
         if not single and target.stride(-1) != 1:
             target = target.contiguous()
-        loss, d_x, d_t = _lib.sce_fwd_bwd(x, x.shape[1], target, single, mask_idx, alpha)
+        loss, d_x, d_t = _lib.sce_fwd_bwd(x, n_dim, target, single, mask_idx, alpha)
         ctx.single = single
         ctx.save_for_backward(d_x, d_t)
         ctx.t_shape = target.shape
@@ -33,12 +33,14 @@ class _SCEMaskedFn(torch.autograd.Function):
             if not ctx.single:
                 raise NotImplementedError("gradient w.r.t. a per-row SCE target is not needed by MAGIC")
             gt = (d_t * g).view(ctx.t_shape)
-        return gx, gt, None, None
+        return gx, gt, None, None, None
 
 
-def sce_loss_masked(x, target, mask_idx, alpha=3):
-    """SCE over the rows ``mask_idx`` of ``x`` without materialising the gathered rows."""
-    return _SCEMaskedFn.apply(x, target, mask_idx, float(alpha))
+def sce_loss_masked(x, target, mask_idx, alpha=3, n_dim=None):
+    """SCE over the rows ``mask_idx`` of ``x`` without materialising the gathered rows.  With
+    ``n_dim`` only the first ``n_dim`` columns of ``x`` (and of the target) are features, the rest
+    is padding whose gradient is zero."""
+    return _SCEMaskedFn.apply(x, target, mask_idx, float(alpha), int(n_dim if n_dim is not None else x.shape[1]))
 
 
 def sce_loss(x, y, alpha=3):
@@ -48,4 +50,4 @@ def sce_loss(x, y, alpha=3):
     idx = torch.arange(x.shape[0], device=x.device)
     if y.requires_grad:
         raise NotImplementedError("gradient w.r.t. a per-row SCE target is not needed by MAGIC")
-    return _SCEMaskedFn.apply(x, y, idx, float(alpha))
+    return _SCEMaskedFn.apply(x, y, idx, float(alpha), x.shape[1])
