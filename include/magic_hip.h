@@ -176,8 +176,12 @@ int magic_gat_fwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t hea
  *   d_pre  [N,ld_dpre] gradient w.r.t. the pre-activation (= gradient of the residual input)
  *   d_y    [N,ld_dy] cols [0,C) d_hs, [C,C+H) d_eh, [C+H,C+2H) d_et  (C = H*D)
  *   d_ee_table [e_dim,H] (when etype_csc != NULL)   -- fixed-order reduction, no atomics
- *   edge_rec [E,2H]  CSC order: {a[0..H), d_logit[0..H)}; d_logit is the gradient w.r.t.
- *                    ee[e,:] for the dense-ee path
+ *   d_logit [E,H]   CSC order: gradient w.r.t. the attention logit of every edge and head
+ *                    (= gradient w.r.t. ee[e,:] on the dense-ee path)
+ * The sweep gathers one node row per edge: in source (CSR) order it reads d_pre[dst] once and
+ * uses it for d_hs[src] += a d_pre[dst] and for the SDDMM term <hs[src], d_pre[dst]>; the
+ * softmax backward then only streams [E,H] arrays.  in_src is not read (kept for symmetry
+ * with magic_gat_fwd).  d_pre may alias d_out when prelu_w is NULL (no copy is made).
  *   d_bias [H*D] (optional), d_prelu_w [1] (optional)
  * ---------------------------------------------------------------------------------- */
 size_t magic_gat_bwd_workspace_bytes(int32_t n_nodes, int32_t n_edges, int32_t n_chunks_in,
@@ -193,7 +197,7 @@ int magic_gat_bwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t hea
                   const float *prelu_w,
                   const float *d_out, int64_t ld_dout,
                   float *d_pre, int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table,
-                  float *edge_rec,
+                  float *d_logit,
                   float *d_bias, float *d_prelu_w,
                   void *workspace, size_t workspace_bytes, void *stream);
 

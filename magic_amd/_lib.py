@@ -308,13 +308,13 @@ def gat_bwd(struct, H: int, D: int, hs, attn, etype_csc, e_dim: int, slope: floa
             d_pre, d_y, want_bias: bool):
     """Fills d_pre [N,>=C] and d_y [N,>=C+2H] (views allowed, unit inner stride); with
     ``prelu_w is None`` ``d_pre`` may be the very tensor passed as ``d_out`` (no copy is made).
-    Returns (d_ee_table | None, edge_rec [E,2H], d_bias | None, d_prelu_w | None)."""
+    Returns (d_ee_table | None, d_logit [E,H] in CSC order, d_bias | None, d_prelu_w | None)."""
     lib = load()
     from .graph import LIGHT_MAX
     N, E = struct.num_nodes, struct.num_edges
     dev = hs.device
     Cc = H * D
-    rec = torch.empty(E, 2 * H, dtype=torch.float32, device=dev)
+    rec = torch.empty(E, H, dtype=torch.float32, device=dev)   # d_logit per edge and head, CSC order
     d_table = torch.empty(e_dim, H, dtype=torch.float32, device=dev) if etype_csc is not None else None
     d_bias = torch.empty(Cc, dtype=torch.float32, device=dev) if want_bias else None
     d_prelu = torch.empty(1, dtype=torch.float32, device=dev) if prelu_w is not None else None

@@ -1,9 +1,13 @@
-// GAT layer, edge phase, backward.  Two segmented sweeps, no atomics:
-//   destination sweep (CSC): PReLU / bias adjoints, d_a = <hs[src], d_pre[dst]>, softmax
-//     backward d_logit = a (d_a - sum_seg a d_a), leaky-ReLU', d_et, and the per-edge record
-//     {a, d_logit} the source sweep reads;
-//   source sweep (CSR): d_hs[u] = sum_{e: src e = u} a_e d_pre[dst e], d_eh[u] = sum d_logit.
-// Then a fixed-order reduction of d_logit per edge type for the edge-score table.
+// GAT layer, edge phase, backward.  Segmented sweeps, no atomics, one gather of node rows:
+//   node adjoint      PReLU / bias adjoints of the incoming gradient (skipped when the caller
+//                     already holds the pre-activation gradient);
+//   source sweep      (CSR) per edge u->v gathers d_pre[v] once and uses it twice:
+//                     d_hs[u] += a_e d_pre[v]   and   t_e = <hs[u], d_pre[v]> per head
+//                     (hs[u] is the sweep's own row), t_e stored at the edge's CSC position;
+//   destination pass  (CSC, streams [E,H] arrays only) softmax backward
+//                     d_logit_e = a_e (t_e - sum_seg a t) * leaky', d_et[v] = sum_seg d_logit;
+//   source pass 2     d_eh[u] = sum over out-edges of d_logit (16-byte gathers);
+//   then a fixed-order reduction of d_logit per edge type for the edge-score table.
 #include "gat_common.h"
 
 namespace magic {
@@ -12,12 +16,11 @@ struct BwdArgs {
     int N, E;
     PlanDev pin;   // CSC plan
     PlanDev pout;  // CSR plan
-    const int32_t *in_src;
     const int32_t *out_dst;
     const int32_t *out_pos;
     const float *hs;
     int64_t ld_hs;
-    const float *attn;  // [E,H] packed (sign bit = logit not positive)
+    const float *attn;  // [E,H] packed (sign bit = logit not positive), CSC order
     const int32_t *etype;
     int e_dim;
     float slope;
@@ -32,10 +35,11 @@ struct BwdArgs {
     float *d_y;
     int64_t ld_dy;
     float *d_table;  // [e_dim,H]
-    float *rec;      // [E,2H]
+    float *dl;       // [E,H] d_logit, CSC order
     float *d_bias;   // [C]
     float *d_prelu;  // [1]
     // workspace
+    float *t;         // [E,H] <hs[src], d_pre[dst]> per head, CSC order
     float *ws_bias;   // [grid_light, C]
     float *ws_prelu;  // [grid_light]
     int grid_light;
@@ -47,27 +51,26 @@ struct BwdArgs {
     int grid_table;
 };
 
-// ---- destination sweep, light segments + node-level adjoints for EVERY node -------------
+// ---- node adjoint: d_pre = d_out * PReLU'(pre), column sums (bias gradient), slope gradient ---
 template <int H, int LPH>
-__global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a) {
+__global__ __launch_bounds__(256) void k_bwd_node_adjoint(BwdArgs a) {
     constexpr int G = H * LPH;
     constexpr int NPB = 256 / G;
     constexpr int C = G * 4;
     __shared__ float4 red4[256];
     __shared__ float red1[256];
     const int g = threadIdx.x % G;
-    const int h = g / LPH;
     const int slot = threadIdx.x / G;
     const float pw = a.prelu_w ? a.prelu_w[0] : 1.f;
+    const float iw = pw > 0.f ? 1.f / pw : 0.f;
     float4 bsum = f4zero();
     float wsum = 0.f;
     for (int v = blockIdx.x * NPB + slot; v < a.N; v += gridDim.x * NPB) {
         float4 go = ld4(a.d_out + (int64_t)v * a.ld_dout + g * 4);
         if (a.prelu_w) {
             float4 p;
-            if (pw > 0.f) {
+            if (pw > 0.f) {  // PReLU is invertible for a positive slope
                 p = ld4(a.act_out + (int64_t)v * a.ld_act + g * 4);
-                const float iw = 1.f / pw;
                 p.x = p.x > 0.f ? p.x : p.x * iw;
                 p.y = p.y > 0.f ? p.y : p.y * iw;
                 p.z = p.z > 0.f ? p.z : p.z * iw;
@@ -84,91 +87,8 @@ __global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a) {
         }
         if (a.d_pre != a.d_out) st4(a.d_pre + (int64_t)v * a.ld_dpre + g * 4, go);
         add4(bsum, go);
-        const int b = a.pin.ptr[v], e = a.pin.ptr[v + 1];
-        if (e - b > a.pin.light_max) continue;
-        if (e - b <= 4) {
-            // short segment (the common case): everything stays in registers, one batch of
-            // clamped loads, the record is written once
-            const int deg = e - b;
-            float det = 0.f;
-            if (deg > 0) {
-                float4 r[4];
-                float ap[4], da[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ii = min(b + j, e - 1);
-                    r[j] = ld4(a.hs + (int64_t)a.in_src[ii] * a.ld_hs + g * 4);
-                    ap[j] = a.attn[(int64_t)ii * H + h];
-                }
-                float delta = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    da[j] = head_sum<LPH>(dot4(r[j], go));
-                    delta = j < deg ? fmaf(fabsf(ap[j]), da[j], delta) : delta;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j < deg) {
-                        const float aw = fabsf(ap[j]);
-                        float dl = aw * (da[j] - delta);
-                        if (attn_neg(ap[j])) dl *= a.slope;
-                        a.rec[(int64_t)(b + j) * 2 * H + h] = aw;
-                        a.rec[(int64_t)(b + j) * 2 * H + H + h] = dl;
-                        det += dl;
-                    }
-                }
-            }
-            if ((g % LPH) == 0) a.d_y[(int64_t)v * a.ld_dy + C + H + h] = det;
-            continue;
-        }
-        // sweep 1: d_a per edge (parked in the record's d_logit slot) and delta = sum a d_a
-        float delta = 0.f;
-        int i = b;
-        for (; i + 4 <= e; i += 4) {
-            float4 r[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)a.in_src[i + j] * a.ld_hs + g * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float da = head_sum<LPH>(dot4(r[j], go));
-                float aw = fabsf(a.attn[(int64_t)(i + j) * H + h]);
-                delta = fmaf(aw, da, delta);
-                a.rec[(int64_t)(i + j) * 2 * H + H + h] = da;
-            }
-        }
-        if (i < e) {  // tail of 1..3 edges as one clamped batch
-            float4 r[3];
-            float aw[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int ii = min(i + j, e - 1);
-                r[j] = ld4(a.hs + (int64_t)a.in_src[ii] * a.ld_hs + g * 4);
-                aw[j] = fabsf(a.attn[(int64_t)ii * H + h]);
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float da = head_sum<LPH>(dot4(r[j], go));
-                if (i + j < e) {
-                    delta = fmaf(aw[j], da, delta);
-                    a.rec[(int64_t)(i + j) * 2 * H + H + h] = da;
-                }
-            }
-        }
-        // sweep 2: d_logit (every lane re-reads the value it stored itself)
-        float det = 0.f;
-        for (i = b; i < e; ++i) {
-            float ap = a.attn[(int64_t)i * H + h];
-            float aw = fabsf(ap);
-            float da = a.rec[(int64_t)i * 2 * H + H + h];
-            float dl = aw * (da - delta);
-            if (attn_neg(ap)) dl *= a.slope;
-            a.rec[(int64_t)i * 2 * H + h] = aw;
-            a.rec[(int64_t)i * 2 * H + H + h] = dl;
-            det += dl;
-        }
-        if ((g % LPH) == 0) a.d_y[(int64_t)v * a.ld_dy + C + H + h] = det;
     }
-    // per-block partials of d_bias (per channel) and d_prelu_w, summed in slot order
+    // per-block partials, summed in slot order
     red4[threadIdx.x] = bsum;
     red1[threadIdx.x] = wsum;
     __syncthreads();
@@ -209,44 +129,217 @@ __global__ __launch_bounds__(256) void k_bwd_reduce_bias(BwdArgs a, int C) {
     }
 }
 
-// ---- destination sweep, heavy segments ---------------------------------------------------
-// step 1: wave per chunk, lane groups take edges round robin: d_a and the chunk's delta
+// ---- source sweep --------------------------------------------------------------------------
+// One lane group per source node u with <= light_max out-edges.  Per edge: the destination's
+// gradient row is gathered once; a_e comes from the edge's CSC slot, t_e goes back to it.
 template <int H, int LPH>
-__global__ __launch_bounds__(256) void k_bwd_dst_heavy1(BwdArgs a) {
+__global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
+    constexpr int G = H * LPH;
+    constexpr int NPB = 256 / G;
+    const int g = threadIdx.x % G;
+    const int h = g / LPH;
+    const bool writer = (g % LPH) == 0;
+    const int slot = threadIdx.x / G;
+    for (int u = blockIdx.x * NPB + slot; u < a.N; u += gridDim.x * NPB) {
+        const int b = a.pout.ptr[u], e = a.pout.ptr[u + 1];
+        if (e - b > a.pout.light_max) continue;
+        const float4 hu = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
+        float4 acc = f4zero();
+        for (int j = b; j < e; j += 4) {  // batches of 4 with clamped indices: loads stay unconditional
+            int pos[4];
+            float4 r[4];
+            float w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int jj = min(j + k, e - 1);
+                pos[k] = a.out_pos[jj];
+                r[k] = ld4(a.d_pre + (int64_t)a.out_dst[jj] * a.ld_dpre + g * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = fabsf(a.attn[(int64_t)pos[k] * H + h]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float tt = head_sum<LPH>(dot4(r[k], hu));
+                if (j + k < e) {
+                    if (writer) a.t[(int64_t)pos[k] * H + h] = tt;
+                    fma4(acc, w[k], r[k]);
+                }
+            }
+        }
+        st4(a.d_y + (int64_t)u * a.ld_dy + g * 4, acc);
+    }
+}
+
+template <int H, int LPH>
+__global__ __launch_bounds__(256) void k_bwd_src_heavy1(BwdArgs a) {
     constexpr int G = H * LPH;
     constexpr int NSG = 64 / G;
     constexpr int C = G * 4;
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= a.pin.n_chunks) return;
-    const int v = a.pin.heavy_node[a.pin.chunk_node[c]];
-    const int beg = a.pin.chunk_beg[c], end = a.pin.chunk_end[c];
+    if (c >= a.pout.n_chunks) return;
+    const int u = a.pout.heavy_node[a.pout.chunk_node[c]];
+    const int beg = a.pout.chunk_beg[c], end = a.pout.chunk_end[c];
     const int g = lane % G, sg = lane / G, h = g / LPH;
-    const float4 go = ld4(a.d_pre + (int64_t)v * a.ld_dpre + g * 4);
-    float delta = 0.f;
-    int i = beg + sg;
-    for (; i + 3 * NSG < end; i += 4 * NSG) {
+    const bool writer = (g % LPH) == 0;
+    const float4 hu = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
+    float4 acc = f4zero();
+    for (int j = beg + sg; j < end; j += 4 * NSG) {
+        int pos[4];
         float4 r[4];
+        float w[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)a.in_src[i + j * NSG] * a.ld_hs + g * 4);
+        for (int k = 0; k < 4; ++k) {
+            const int jj = min(j + k * NSG, end - 1);
+            pos[k] = a.out_pos[jj];
+            r[k] = ld4(a.d_pre + (int64_t)a.out_dst[jj] * a.ld_dpre + g * 4);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float da = head_sum<LPH>(dot4(r[j], go));
-            delta = fmaf(fabsf(a.attn[(int64_t)(i + j * NSG) * H + h]), da, delta);
-            a.rec[(int64_t)(i + j * NSG) * 2 * H + H + h] = da;
+        for (int k = 0; k < 4; ++k) w[k] = fabsf(a.attn[(int64_t)pos[k] * H + h]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float tt = head_sum<LPH>(dot4(r[k], hu));
+            if (j + k * NSG < end) {
+                if (writer) a.t[(int64_t)pos[k] * H + h] = tt;
+                fma4(acc, w[k], r[k]);
+            }
         }
     }
-    for (; i < end; i += NSG) {
-        float4 r = ld4(a.hs + (int64_t)a.in_src[i] * a.ld_hs + g * 4);
-        float da = head_sum<LPH>(dot4(r, go));
-        delta = fmaf(fabsf(a.attn[(int64_t)i * H + h]), da, delta);
-        a.rec[(int64_t)i * 2 * H + H + h] = da;
-    }
-    delta = substream_sum<G>(delta);
-    if (sg == 0 && (g % LPH) == 0) a.ws_delta[(int64_t)c * H + h] = delta;
+    acc = substream_sum4<G>(acc);
+    if (sg == 0) st4(a.ws_acc + (int64_t)c * C + g * 4, acc);
 }
 
-// step 2: wave per chunk, lane per edge: node delta (chunk order), d_logit, record, chunk d_et
+template <int H, int LPH>
+__global__ __launch_bounds__(256) void k_bwd_src_heavy2(BwdArgs a) {
+    constexpr int G = H * LPH;
+    constexpr int NSGB = 256 / G;
+    constexpr int C = G * 4;
+    __shared__ float4 part[256];
+    const int slot = blockIdx.x;
+    const int g = threadIdx.x % G, sg = threadIdx.x / G;
+    const int c0 = a.pout.heavy_cptr[slot], c1 = a.pout.heavy_cptr[slot + 1];
+    const int u = a.pout.heavy_node[slot];
+    float4 acc = f4zero();
+    for (int c = c0 + sg; c < c1; c += NSGB) add4(acc, ld4(a.ws_acc + (int64_t)c * C + g * 4));
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (sg == 0) {
+        for (int k = 1; k < NSGB; ++k) add4(acc, part[k * G + g]);
+        st4(a.d_y + (int64_t)u * a.ld_dy + g * 4, acc);
+    }
+}
+
+// ---- destination pass: softmax backward over the streamed [E,H] arrays -----------------------
+template <int H> struct HeadVec {
+    float v[H];
+};
+template <int H> __device__ __forceinline__ HeadVec<H> ldh(const float *p) {
+    HeadVec<H> r;
+    if (H == 4) {
+        const float4 q = *reinterpret_cast<const float4 *>(p);
+        r.v[0] = q.x, r.v[1 % H] = q.y, r.v[2 % H] = q.z, r.v[3 % H] = q.w;
+    } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h) r.v[h] = p[h];
+    }
+    return r;
+}
+template <int H> __device__ __forceinline__ void sth(float *p, const HeadVec<H> &r) {
+    if (H == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(r.v[0], r.v[1 % H], r.v[2 % H], r.v[3 % H]);
+    } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h) p[h] = r.v[h];
+    }
+}
+
+// one thread per destination node with <= light_max in-edges
+template <int H>
+__global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a, int C) {
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < a.N; v += gridDim.x * 256) {
+        const int b = a.pin.ptr[v], e = a.pin.ptr[v + 1];
+        if (e - b > a.pin.light_max) continue;
+        HeadVec<H> delta, det;
+#pragma unroll
+        for (int h = 0; h < H; ++h) delta.v[h] = det.v[h] = 0.f;
+        if (e == b) {
+            sth<H>(a.d_y + (int64_t)v * a.ld_dy + C + H, det);
+            continue;
+        }
+        if (e - b <= 4) {
+            // short segment (the common case): one batch of clamped loads, everything in registers
+            HeadVec<H> ap[4], tt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ii = min(b + k, e - 1);
+                ap[k] = ldh<H>(a.attn + (int64_t)ii * H);
+                tt[k] = ldh<H>(a.t + (int64_t)ii * H);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+                    delta.v[h] = b + k < e ? fmaf(fabsf(ap[k].v[h]), tt[k].v[h], delta.v[h]) : delta.v[h];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (b + k < e) {
+                    HeadVec<H> dl;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        float d = fabsf(ap[k].v[h]) * (tt[k].v[h] - delta.v[h]);
+                        if (attn_neg(ap[k].v[h])) d *= a.slope;
+                        dl.v[h] = d;
+                        det.v[h] += d;
+                    }
+                    sth<H>(a.dl + (int64_t)(b + k) * H, dl);
+                }
+            }
+        } else {
+            for (int i = b; i < e; ++i) {
+                const HeadVec<H> ap = ldh<H>(a.attn + (int64_t)i * H), tt = ldh<H>(a.t + (int64_t)i * H);
+#pragma unroll
+                for (int h = 0; h < H; ++h) delta.v[h] = fmaf(fabsf(ap.v[h]), tt.v[h], delta.v[h]);
+            }
+            for (int i = b; i < e; ++i) {
+                const HeadVec<H> ap = ldh<H>(a.attn + (int64_t)i * H), tt = ldh<H>(a.t + (int64_t)i * H);
+                HeadVec<H> dl;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    float d = fabsf(ap.v[h]) * (tt.v[h] - delta.v[h]);
+                    if (attn_neg(ap.v[h])) d *= a.slope;
+                    dl.v[h] = d;
+                    det.v[h] += d;
+                }
+                sth<H>(a.dl + (int64_t)i * H, dl);
+            }
+        }
+        sth<H>(a.d_y + (int64_t)v * a.ld_dy + C + H, det);
+    }
+}
+
+// heavy destinations, step 1: wave per chunk, lane per edge: the chunk's sum of a * t
+template <int H>
+__global__ __launch_bounds__(256) void k_bwd_dst_heavy1(BwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= a.pin.n_chunks) return;
+    const int beg = a.pin.chunk_beg[c], end = a.pin.chunk_end[c];
+    float delta[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) delta[h] = 0.f;
+    for (int i = beg + lane; i < end; i += 64) {
+        const HeadVec<H> ap = ldh<H>(a.attn + (int64_t)i * H), tt = ldh<H>(a.t + (int64_t)i * H);
+#pragma unroll
+        for (int h = 0; h < H; ++h) delta[h] = fmaf(fabsf(ap.v[h]), tt.v[h], delta[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const float d = wave_sum(delta[h]);
+        if (lane == 0) a.ws_delta[(int64_t)c * H + h] = d;
+    }
+}
+
+// step 2: wave per chunk, lane per edge: node delta (chunk order), d_logit, chunk d_et
 template <int H>
 __global__ __launch_bounds__(256) void k_bwd_dst_heavy2(BwdArgs a) {
     const int lane = threadIdx.x & 63;
@@ -264,17 +357,16 @@ __global__ __launch_bounds__(256) void k_bwd_dst_heavy2(BwdArgs a) {
         det[h] = 0.f;
     }
     for (int i = beg + lane; i < end; i += 64) {
+        const HeadVec<H> ap = ldh<H>(a.attn + (int64_t)i * H), tt = ldh<H>(a.t + (int64_t)i * H);
+        HeadVec<H> dl;
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            float ap = a.attn[(int64_t)i * H + h];
-            float aw = fabsf(ap);
-            float da = a.rec[(int64_t)i * 2 * H + H + h];
-            float dl = aw * (da - delta[h]);
-            if (attn_neg(ap)) dl *= a.slope;
-            a.rec[(int64_t)i * 2 * H + h] = aw;
-            a.rec[(int64_t)i * 2 * H + H + h] = dl;
-            det[h] += dl;
+            float d = fabsf(ap.v[h]) * (tt.v[h] - delta[h]);
+            if (attn_neg(ap.v[h])) d *= a.slope;
+            dl.v[h] = d;
+            det[h] += d;
         }
+        sth<H>(a.dl + (int64_t)i * H, dl);
     }
 #pragma unroll
     for (int h = 0; h < H; ++h) {
@@ -300,131 +392,62 @@ __global__ __launch_bounds__(256) void k_bwd_dst_heavy3(BwdArgs a, int C) {
     }
 }
 
-// ---- source sweep ------------------------------------------------------------------------
-template <int H, int LPH>
-__global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
-    constexpr int G = H * LPH;
-    constexpr int NPB = 256 / G;
-    constexpr int C = G * 4;
-    const int g = threadIdx.x % G;
-    const int h = g / LPH;
-    const int slot = threadIdx.x / G;
-    for (int u = blockIdx.x * NPB + slot; u < a.N; u += gridDim.x * NPB) {
+// ---- source pass 2: d_eh[u] = sum over out-edges of d_logit -----------------------------------
+template <int H>
+__global__ __launch_bounds__(256) void k_bwd_deh_light(BwdArgs a, int C) {
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < a.N; u += gridDim.x * 256) {
         const int b = a.pout.ptr[u], e = a.pout.ptr[u + 1];
         if (e - b > a.pout.light_max) continue;
-        float4 acc = f4zero();
-        float deh = 0.f;
-        int j = b;
-        for (; j + 4 <= e; j += 4) {
-            int pos[4];
-            float4 r[4];
-            float w[4], dl[4];
+        HeadVec<H> s;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) pos[t] = a.out_pos[j + t];
+        for (int h = 0; h < H; ++h) s.v[h] = 0.f;
+        for (int j = b; j < e; j += 4) {
+            HeadVec<H> d[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) r[t] = ld4(a.d_pre + (int64_t)a.out_dst[j + t] * a.ld_dpre + g * 4);
+            for (int k = 0; k < 4; ++k) d[k] = ldh<H>(a.dl + (int64_t)a.out_pos[min(j + k, e - 1)] * H);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                w[t] = a.rec[(int64_t)pos[t] * 2 * H + h];
-                dl[t] = a.rec[(int64_t)pos[t] * 2 * H + H + h];
-            }
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                fma4(acc, w[t], r[t]);
-                deh += dl[t];
-            }
+                for (int h = 0; h < H; ++h) s.v[h] += j + k < e ? d[k].v[h] : 0.f;
         }
-        if (j < e) {  // tail of 1..3 edges as one clamped batch
-            float4 r[3];
-            float w[3], dl[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int jj = min(j + t, e - 1);
-                const int pos = a.out_pos[jj];
-                r[t] = ld4(a.d_pre + (int64_t)a.out_dst[jj] * a.ld_dpre + g * 4);
-                w[t] = a.rec[(int64_t)pos * 2 * H + h];
-                dl[t] = a.rec[(int64_t)pos * 2 * H + H + h];
-            }
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                if (j + t < e) {
-                    fma4(acc, w[t], r[t]);
-                    deh += dl[t];
-                }
-            }
-        }
-        st4(a.d_y + (int64_t)u * a.ld_dy + g * 4, acc);
-        if ((g % LPH) == 0) a.d_y[(int64_t)u * a.ld_dy + C + h] = deh;
+        sth<H>(a.d_y + (int64_t)u * a.ld_dy + C, s);
     }
 }
 
-template <int H, int LPH>
-__global__ __launch_bounds__(256) void k_bwd_src_heavy1(BwdArgs a) {
-    constexpr int G = H * LPH;
-    constexpr int NSG = 64 / G;
-    constexpr int C = G * 4;
+template <int H>
+__global__ __launch_bounds__(256) void k_bwd_deh_heavy1(BwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= a.pout.n_chunks) return;
     const int beg = a.pout.chunk_beg[c], end = a.pout.chunk_end[c];
-    const int g = lane % G, sg = lane / G, h = g / LPH;
-    float4 acc = f4zero();
-    float deh = 0.f;
-    int j = beg + sg;
-    for (; j + 3 * NSG < end; j += 4 * NSG) {
-        int pos[4];
-        float4 r[4];
+    float s[H];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) pos[t] = a.out_pos[j + t * NSG];
+    for (int h = 0; h < H; ++h) s[h] = 0.f;
+    for (int j = beg + lane; j < end; j += 64) {
+        const HeadVec<H> d = ldh<H>(a.dl + (int64_t)a.out_pos[j] * H);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) r[t] = ld4(a.d_pre + (int64_t)a.out_dst[j + t * NSG] * a.ld_dpre + g * 4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            fma4(acc, a.rec[(int64_t)pos[t] * 2 * H + h], r[t]);
-            deh += a.rec[(int64_t)pos[t] * 2 * H + H + h];
-        }
+        for (int h = 0; h < H; ++h) s[h] += d.v[h];
     }
-    for (; j < end; j += NSG) {
-        int pos = a.out_pos[j];
-        float4 r = ld4(a.d_pre + (int64_t)a.out_dst[j] * a.ld_dpre + g * 4);
-        fma4(acc, a.rec[(int64_t)pos * 2 * H + h], r);
-        deh += a.rec[(int64_t)pos * 2 * H + H + h];
-    }
-    acc = substream_sum4<G>(acc);
-    deh = substream_sum<G>(deh);
-    if (sg == 0) {
-        st4(a.ws_acc + (int64_t)c * C + g * 4, acc);
-        if ((g % LPH) == 0) a.ws_deh[(int64_t)c * H + h] = deh;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const float t = wave_sum(s[h]);
+        if (lane == 0) a.ws_deh[(int64_t)c * H + h] = t;
     }
 }
 
-template <int H, int LPH>
-__global__ __launch_bounds__(256) void k_bwd_src_heavy2(BwdArgs a) {
-    constexpr int G = H * LPH;
-    constexpr int NSGB = 256 / G;
-    constexpr int C = G * 4;
-    __shared__ float4 part[256];
-    __shared__ float part1[256];
-    const int slot = blockIdx.x;
-    const int g = threadIdx.x % G, sg = threadIdx.x / G, h = g / LPH;
+template <int H>
+__global__ __launch_bounds__(256) void k_bwd_deh_heavy2(BwdArgs a, int C) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= a.pout.n_heavy) return;
     const int c0 = a.pout.heavy_cptr[slot], c1 = a.pout.heavy_cptr[slot + 1];
     const int u = a.pout.heavy_node[slot];
-    float4 acc = f4zero();
-    float deh = 0.f;
-    for (int c = c0 + sg; c < c1; c += NSGB) {
-        add4(acc, ld4(a.ws_acc + (int64_t)c * C + g * 4));
-        deh += a.ws_deh[(int64_t)c * H + h];
-    }
-    part[threadIdx.x] = acc;
-    part1[threadIdx.x] = deh;
-    __syncthreads();
-    if (sg == 0) {
-        for (int k = 1; k < NSGB; ++k) {
-            add4(acc, part[k * G + g]);
-            deh += part1[k * G + g];
-        }
-        st4(a.d_y + (int64_t)u * a.ld_dy + g * 4, acc);
-        if ((g % LPH) == 0) a.d_y[(int64_t)u * a.ld_dy + C + h] = deh;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float t = 0.f;
+        for (int k = c0 + lane; k < c1; k += 64) t += a.ws_deh[(int64_t)k * H + h];
+        t = wave_sum(t);
+        if (lane == 0) a.d_y[(int64_t)u * a.ld_dy + C + h] = t;
     }
 }
 
@@ -443,7 +466,7 @@ __global__ __launch_bounds__(256) void k_bwd_table_partial(BwdArgs a) {
         const int ty = a.etype[i];
         float dl[H];
 #pragma unroll
-        for (int h = 0; h < H; ++h) dl[h] = a.rec[(int64_t)i * 2 * H + H + h];
+        for (int h = 0; h < H; ++h) dl[h] = a.dl[(int64_t)i * H + h];
 #pragma unroll
         for (int t = 0; t < TMAX; ++t)
 #pragma unroll
@@ -505,29 +528,35 @@ int launch_table(BwdArgs &a, hipStream_t stream) {
 template <int H, int LPH>
 int launch_bwd(BwdArgs &a, hipStream_t stream) {
     constexpr int C = H * LPH * 4;
-    MAGIC_LAUNCH("gat_bwd_dst_light", (k_bwd_dst_light<H, LPH>), a.grid_light, 256, 0, stream, a);
-    if (a.d_bias || a.d_prelu) MAGIC_LAUNCH("gat_bwd_reduce_bias", k_bwd_reduce_bias, C + 1, 256, 0, stream, a, C);
+    constexpr int NPB = 256 / (H * LPH);
+    if (a.prelu_w || a.d_bias || a.d_pre != a.d_out) {
+        MAGIC_LAUNCH("gat_bwd_node_adjoint", (k_bwd_node_adjoint<H, LPH>), a.grid_light, 256, 0, stream, a);
+        if (a.d_bias || a.d_prelu)
+            MAGIC_LAUNCH("gat_bwd_reduce_bias", k_bwd_reduce_bias, C + 1, 256, 0, stream, a, C);
+    }
+    MAGIC_LAUNCH("gat_bwd_src_light", (k_bwd_src_light<H, LPH>), stride_grid(a.N, NPB, 256 * 16), 256, 0, stream, a);
+    if (a.pout.n_chunks > 0) {
+        const int cgrid = (a.pout.n_chunks + 3) / 4;
+        MAGIC_LAUNCH("gat_bwd_src_heavy1", (k_bwd_src_heavy1<H, LPH>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH("gat_bwd_src_heavy2", (k_bwd_src_heavy2<H, LPH>), a.pout.n_heavy, 256, 0, stream, a);
+    }
+    const int ngrid = stride_grid(a.N, 256, 256 * 16);
+    MAGIC_LAUNCH("gat_bwd_dst_light", (k_bwd_dst_light<H>), ngrid, 256, 0, stream, a, C);
     if (a.pin.n_chunks > 0) {
-        int cgrid = (a.pin.n_chunks + 3) / 4;
-        MAGIC_LAUNCH("gat_bwd_dst_heavy1", (k_bwd_dst_heavy1<H, LPH>), cgrid, 256, 0, stream, a);
+        const int cgrid = (a.pin.n_chunks + 3) / 4;
+        MAGIC_LAUNCH("gat_bwd_dst_heavy1", (k_bwd_dst_heavy1<H>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_bwd_dst_heavy2", (k_bwd_dst_heavy2<H>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_bwd_dst_heavy3", (k_bwd_dst_heavy3<H>), (a.pin.n_heavy + 3) / 4, 256, 0, stream, a, C);
     }
-    {
-        constexpr int NPB = 256 / (H * LPH);
-        int grid = stride_grid(a.N, NPB, 256 * 16);
-        MAGIC_LAUNCH("gat_bwd_src_light", (k_bwd_src_light<H, LPH>), grid, 256, 0, stream, a);
-    }
+    MAGIC_LAUNCH("gat_bwd_deh_light", (k_bwd_deh_light<H>), ngrid, 256, 0, stream, a, C);
     if (a.pout.n_chunks > 0) {
-        int cgrid = (a.pout.n_chunks + 3) / 4;
-        MAGIC_LAUNCH("gat_bwd_src_heavy1", (k_bwd_src_heavy1<H, LPH>), cgrid, 256, 0, stream, a);
-        MAGIC_LAUNCH("gat_bwd_src_heavy2", (k_bwd_src_heavy2<H, LPH>), a.pout.n_heavy, 256, 0, stream, a);
+        MAGIC_LAUNCH("gat_bwd_deh_heavy1", (k_bwd_deh_heavy1<H>), (a.pout.n_chunks + 3) / 4, 256, 0, stream, a);
+        MAGIC_LAUNCH("gat_bwd_deh_heavy2", (k_bwd_deh_heavy2<H>), (a.pout.n_heavy + 3) / 4, 256, 0, stream, a, C);
     }
     int st = launch_table<H>(a, stream);
     if (st != MAGIC_OK) return st;
     return launch_status();
 }
-
 static int light_grid(int N, int H, int D) {
     int npb = 256 / (H * D / 4);
     return stride_grid(N, npb, 2048);
@@ -549,6 +578,7 @@ size_t magic_gat_bwd_workspace_bytes(int32_t N, int32_t E, int32_t n_chunks_in, 
     b += align_up((size_t)(n_chunks_out > 0 ? n_chunks_out : 1) * C * f) +
          align_up((size_t)(n_chunks_out > 0 ? n_chunks_out : 1) * H * f);
     b += align_up(gt * (size_t)(e_dim > 0 ? e_dim : 1) * H * f);
+    b += align_up((size_t)(E > 0 ? E : 1) * H * f);
     return b + 256;
 }
 
@@ -557,7 +587,7 @@ int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
                   int64_t ld_hs, const float *attn, const int32_t *etype_csc, int32_t e_dim, float slope,
                   const float *pre, const float *act_out, int64_t ld_act, const float *prelu_w,
                   const float *d_out, int64_t ld_dout, float *d_pre,
-                  int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table, float *edge_rec, float *d_bias, float *d_prelu_w,
+                  int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table, float *d_logit, float *d_bias, float *d_prelu_w,
                   void *workspace, size_t workspace_bytes, void *stream_) {
     using namespace magic;
     if (N < 0 || E < 0 || H <= 0 || D <= 0) return MAGIC_ERR_INVALID_ARG;
@@ -565,7 +595,7 @@ int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     if (N == 0) return MAGIC_OK;
     const int C = H * D;
     if (!plan_valid(in_plan) || !plan_valid(out_plan) || !hs || !d_out || !d_pre || !d_y) return MAGIC_ERR_INVALID_ARG;
-    if (E > 0 && (!in_src || !out_dst || !out_pos || !attn || !edge_rec)) return MAGIC_ERR_INVALID_ARG;
+    if (E > 0 && (!out_dst || !out_pos || !attn || !d_logit)) return MAGIC_ERR_INVALID_ARG;
     if (prelu_w && (!pre || !act_out || ld_act < C || (ld_act & 3))) return MAGIC_ERR_INVALID_ARG;
     if (prelu_w && d_pre == d_out) return MAGIC_ERR_INVALID_ARG;  // in-place only without an activation
     if (ld_hs < C || ld_dout < C || ld_dy < C + 2 * H || ld_dpre < C) return MAGIC_ERR_INVALID_ARG;
@@ -576,7 +606,6 @@ int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     a.E = E;
     a.pin = plan_dev(in_plan);
     a.pout = plan_dev(out_plan);
-    a.in_src = in_src;
     a.out_dst = out_dst;
     a.out_pos = out_pos;
     a.hs = hs;
@@ -596,7 +625,7 @@ int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     a.d_y = d_y;
     a.ld_dy = ld_dy;
     a.d_table = d_ee_table;
-    a.rec = edge_rec;
+    a.dl = d_logit;
     a.d_bias = d_bias;
     a.d_prelu = d_prelu_w;
     a.grid_light = light_grid(N, H, D);
@@ -609,6 +638,7 @@ int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     a.ws_acc = ar.take<float>((size_t)(a.pout.n_chunks > 0 ? a.pout.n_chunks : 1) * C);
     a.ws_deh = ar.take<float>((size_t)(a.pout.n_chunks > 0 ? a.pout.n_chunks : 1) * H);
     a.ws_table = ar.take<float>((size_t)a.grid_table * (e_dim > 0 ? e_dim : 1) * H);
+    a.t = ar.take<float>((size_t)(E > 0 ? E : 1) * H);
     if (!ar.ok()) return MAGIC_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int lph = D / 4;

@@ -103,7 +103,7 @@ class _GATLayerFn(torch.autograd.Function):
                 d_edge = d_table
             else:
                 d_edge = torch.empty(struct.num_edges, H, dtype=torch.float32, device=h.device)
-                d_edge[struct.in_eid.long()] = rec[:, H:]
+                d_edge[struct.in_eid.long()] = rec
         return d_h, d_w, d_edge, d_bias, d_prelu, None, None
 
 
