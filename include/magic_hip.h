@@ -169,6 +169,29 @@ int magic_gat_fwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t hea
                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Operands of magic_proj_fwd / magic_gat_fwd built from the layer's parameters in one launch
+ * (and the adjoint in one launch), replacing the element-wise chain torch would run for
+ * model/gat.py:284-299 and :323:
+ *   w_aug  [H*Dp + 2H (+ H*Dp), F] = [W_fc ; fold(W_fc, attn_h) ; fold(W_fc, attn_t) ; W_res]
+ *          with every head padded from D to Dp rows (zeros),
+ *          fold(W, a)[h, k] = sum_d a[h, d] W[h*D + d, k]
+ *   table  [e_dim, H], table[t, h] = sum_d attn_e[h, d] W_efc[h*D + d, t]
+ *   bias_p [H*Dp] head-padded bias (when bias != NULL)
+ * magic_fold_bwd maps (d_w_aug, d_table, d_bias_p; any may be NULL = zero) back to the
+ * parameter gradients; d_w_res / d_bias may be NULL when the layer has none.
+ * ---------------------------------------------------------------------------------- */
+int magic_fold_fwd(int32_t n_heads, int32_t head_dim, int32_t head_dim_padded, int32_t in_dim,
+                   int32_t e_dim, const float *w_fc, const float *attn_h, const float *attn_t,
+                   const float *w_res, const float *w_efc, const float *attn_e, const float *bias,
+                   float *w_aug, float *table, float *bias_p, void *stream);
+int magic_fold_bwd(int32_t n_heads, int32_t head_dim, int32_t head_dim_padded, int32_t in_dim,
+                   int32_t e_dim, const float *w_fc, const float *attn_h, const float *attn_t,
+                   const float *w_efc, const float *attn_e, const float *d_w_aug,
+                   const float *d_table, const float *d_bias_p, float *d_w_fc, float *d_attn_h,
+                   float *d_attn_t, float *d_w_res, float *d_w_efc, float *d_attn_e, float *d_bias,
+                   void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Backward of magic_gat_fwd (DGL's EdgeSoftmax / GSpMM / GSDDMM backward + the PReLU,
  * bias and residual adjoints that torch autograd runs for model/gat.py:302-335).
  * Inputs: the forward's hs, attn, pre; d_out [N,H*D].

@@ -42,6 +42,8 @@ SYMBOLS = {
     "magic_proj_bwd_weight_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
     "magic_proj_bwd_weight": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_sz,
                                       c_vp]),
+    "magic_fold_fwd": (c_i32, [c_i32] * 5 + [c_vp] * 10 + [c_vp]),
+    "magic_fold_bwd": (c_i32, [c_i32] * 5 + [c_vp] * 15 + [c_vp]),
     "magic_gat_fwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "magic_gat_fwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, c_vp,
                               c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp,
@@ -270,6 +272,39 @@ def proj_bwd_weight(dy: torch.Tensor, x: torch.Tensor, x_mask: Optional[torch.Te
                                      _dev(x, torch.float32, "x"), x.stride(0), _dev(x_mask), float(x_scale),
                                      _dev(dw), ws.data_ptr(), ws.numel(), _stream()), "magic_proj_bwd_weight")
     return dw
+
+
+# ------------------------------------------------------------------------------------- folds
+def fold_fwd(H: int, D: int, Dp: int, w_fc, attn_h, attn_t, w_res, w_efc, attn_e, bias):
+    """(w_aug, table [e_dim,H], bias_p | None) from the layer's parameters; see include/magic_hip.h."""
+    lib = load()
+    F, e_dim = w_fc.shape[1], w_efc.shape[1]
+    dev = w_fc.device
+    Cp = H * Dp
+    rows = Cp + 2 * H + (Cp if w_res is not None else 0)
+    w_aug = torch.empty(rows, F, dtype=torch.float32, device=dev)
+    table = torch.empty(e_dim, H, dtype=torch.float32, device=dev)
+    bias_p = torch.empty(Cp, dtype=torch.float32, device=dev) if bias is not None else None
+    _check(lib.magic_fold_fwd(H, D, Dp, F, e_dim, _dev(w_fc, torch.float32, "w_fc"), _dev(attn_h), _dev(attn_t),
+                              _dev(w_res), _dev(w_efc), _dev(attn_e), _dev(bias), _dev(w_aug), _dev(table),
+                              _dev(bias_p), _stream()), "magic_fold_fwd")
+    return w_aug, table, bias_p
+
+
+def fold_bwd(H: int, D: int, Dp: int, w_fc, attn_h, attn_t, w_efc, attn_e, d_w_aug, d_table, d_bias_p,
+             has_res: bool, has_bias: bool):
+    lib = load()
+    F, e_dim = w_fc.shape[1], w_efc.shape[1]
+    dev = w_fc.device
+    C = H * D
+    new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+    d_w_fc, d_ah, d_at, d_w_efc, d_ae = new(C, F), new(1, H, D), new(1, H, D), new(C, e_dim), new(1, H, D)
+    d_w_res = new(C, F) if has_res else None
+    d_bias = new(1, H, D) if has_bias else None
+    _check(lib.magic_fold_bwd(H, D, Dp, F, e_dim, _dev(w_fc), _dev(attn_h), _dev(attn_t), _dev(w_efc), _dev(attn_e),
+                              _dev(d_w_aug), _dev(d_table), _dev(d_bias_p), _dev(d_w_fc), _dev(d_ah), _dev(d_at),
+                              _dev(d_w_res), _dev(d_w_efc), _dev(d_ae), _dev(d_bias), _stream()), "magic_fold_bwd")
+    return d_w_fc, d_ah, d_at, d_w_res, d_w_efc, d_ae, d_bias
 
 
 # ------------------------------------------------------------------------------------- GAT

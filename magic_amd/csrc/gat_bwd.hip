@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
     for (int u = blockIdx.x * NPB + slot; u < a.N; u += gridDim.x * NPB) {
         const int b = a.pout.ptr[u], e = a.pout.ptr[u + 1];
         if (e - b > a.pout.light_max) continue;
-        const float4 hu = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
+        const float4 hu = ld4_nt(a.hs + (int64_t)u * a.ld_hs + g * 4);
         float4 acc = f4zero();
         for (int j = b; j < e; j += 4) {  // batches of 4 with clamped indices: loads stay unconditional
             int pos[4];
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
                 }
             }
         }
-        st4(a.d_y + (int64_t)u * a.ld_dy + g * 4, acc);
+        st4_nt(a.d_y + (int64_t)u * a.ld_dy + g * 4, acc);
     }
 }
 

@@ -46,6 +46,17 @@ inline bool plan_valid(const magic_plan *p) {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// streaming (read-once / write-once) forms: keep the caches for the gathered node rows
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float *p) {
+    const f4v_t v = __builtin_nontemporal_load(reinterpret_cast<const f4v_t *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4_nt(float *p, float4 v) {
+    f4v_t t;
+    t.x = v.x, t.y = v.y, t.z = v.z, t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<f4v_t *>(p));
+}
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void fma4(float4 &acc, float a, float4 r) {
     acc.x = fmaf(a, r.x, acc.x);

@@ -63,7 +63,7 @@ __device__ __forceinline__ void epilogue(const FwdArgs &a, int v, int g, float4 
     constexpr int C = H * LPH * 4;
     if (a.bias) add4(acc, ld4(a.bias + g * 4));
     if (a.res) {
-        float4 r = ld4(a.res + (int64_t)v * a.ld_res + g * 4);
+        float4 r = ld4_nt(a.res + (int64_t)v * a.ld_res + g * 4);
         if (a.res_mask) {  // residual input = dropout(input): keep mask applied on the fly
             const uchar4 m = *reinterpret_cast<const uchar4 *>(a.res_mask + (int64_t)v * C + g * 4);
             r.x = m.x ? r.x * a.res_scale : 0.f;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
             for (int j = 0; j < 4; ++j) {
                 if (j < deg) {
                     const float w = p[j] * inv;
-                    if (writer) a.attn[(int64_t)(b + j) * H + h] = pack_attn(w, x[j]);
+                    if (writer) __builtin_nontemporal_store(pack_attn(w, x[j]), a.attn + (int64_t)(b + j) * H + h);
                     fma4(acc, w, r[j]);
                 }
             }

@@ -92,6 +92,7 @@ class FusedGMAEFn(torch.autograd.Function):
                                         cfg.etype, None, cfg.slope, bias_d, None, None, False)
         samples = enc[sample_idx]
         ctx.cfg = cfg
+        ctx.set_materialize_grads(False)  # no zero-filled [N, L*C] gradient for the hidden buffer
         ctx.save_for_backward(x_in, sample_idx, enc, rep, hs_d, attn_d, *saved, *params)
         ctx.mark_non_differentiable(enc)
         return enc, recon, samples

@@ -9,9 +9,9 @@ is re-expressed for the MI355X:
   residual projection ``res_fc`` (``:323``) are one fp32 MFMA GEMM against an augmented
   weight ``W_aug = [W_fc ; fold(W_fc, attn_h) ; fold(W_fc, attn_t) ; W_res]`` where
   ``fold(W, a)[h, :] = sum_d a[h, d] * W[h*D + d, :]`` (``eh = (h W^T) . attn_h`` is linear
-  in ``h``, so it is a GEMM column).  The fold is a handful of tiny differentiable torch
-  ops; autograd therefore delivers the gradients of ``fc.weight``, ``attn_h``, ``attn_t``
-  and ``res_fc.weight`` from the single ``d W_aug``.
+  in ``h``, so it is a GEMM column).  ``_FoldFn`` builds ``W_aug`` in one launch and maps the
+  single ``d W_aug`` back to the gradients of ``fc.weight``, ``attn_h``, ``attn_t`` and
+  ``res_fc.weight`` in one launch.
 * edge phase -- ``edge_fc`` + ``attn_e`` (``:297-299``) collapse the same way into a
   ``[e_dim, H]`` table indexed by edge type when ``edata['attr']`` is one-hot (it always is
   in MAGIC: ``utils/loaddata.py:259``), so the reference's ``[E, H*D]`` temporary never
@@ -45,9 +45,30 @@ def _pad_head_dim(d: int) -> int:
     raise _lib.MagicHipError(f"head width {d} > 64 has no compiled kernel")
 
 
-def _fold(w: torch.Tensor, attn: torch.Tensor, H: int, D: int) -> torch.Tensor:
-    """[H*D, F] weight and [1,H,D] attention vector -> [H, F] score weight."""
-    return (w.view(H, D, -1) * attn.view(H, D, 1)).sum(1)
+class _FoldFn(torch.autograd.Function):
+    """Parameters of one layer -> (augmented weight, edge-score table, padded flat bias): one
+    launch forward, one launch backward (``csrc/fold.hip``)."""
+
+    @staticmethod
+    def forward(ctx, w_fc, attn_h, attn_t, w_res, w_efc, attn_e, bias, H, D, Dp):
+        c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        w_fc, attn_h, attn_t, w_res, w_efc, attn_e, bias = map(c, (w_fc, attn_h, attn_t, w_res, w_efc, attn_e, bias))
+        w_aug, table, bias_p = _lib.fold_fwd(H, D, Dp, w_fc, attn_h, attn_t, w_res, w_efc, attn_e, bias)
+        ctx.save_for_backward(w_fc, attn_h, attn_t, w_efc, attn_e)
+        ctx.dims = (H, D, Dp, w_res is not None, bias is not None)
+        ctx.set_materialize_grads(False)
+        if bias_p is None:
+            return w_aug, table
+        return w_aug, table, bias_p
+
+    @staticmethod
+    def backward(ctx, d_w_aug, d_table, d_bias_p=None):
+        w_fc, attn_h, attn_t, w_efc, attn_e = ctx.saved_tensors
+        H, D, Dp, has_res, has_bias = ctx.dims
+        c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        d_w_fc, d_ah, d_at, d_w_res, d_w_efc, d_ae, d_bias = _lib.fold_bwd(
+            H, D, Dp, w_fc, attn_h, attn_t, w_efc, attn_e, c(d_w_aug), c(d_table), c(d_bias_p), has_res, has_bias)
+        return d_w_fc, d_ah, d_at, d_w_res, d_w_efc, d_ae, d_bias, None, None, None
 
 
 class _GATLayerFn(torch.autograd.Function):
@@ -207,43 +228,19 @@ class GATConv(nn.Module):
         self.allow_zero_in_degree = set_value
 
     # ---------------------------------------------------------------------------------
-    def _augmented_weight(self, Dp: int) -> torch.Tensor:
-        H, D = self.n_heads, self.out_feat
-        w = self.fc.weight
-        parts = []
-        if Dp != D:
-            wp = torch.zeros(H, Dp, w.shape[1], dtype=w.dtype, device=w.device)
-            wp[:, :D] = w.view(H, D, -1)
-            parts.append(wp.view(H * Dp, -1))
-        else:
-            parts.append(w)
-        parts.append(_fold(w, self.attn_h, H, D))
-        parts.append(_fold(w, self.attn_t, H, D))
-        if isinstance(self.res_fc, nn.Linear):
-            rw = self.res_fc.weight
-            if Dp != D:
-                rp = torch.zeros(H, Dp, rw.shape[1], dtype=rw.dtype, device=rw.device)
-                rp[:, :D] = rw.view(H, D, -1)
-                rw = rp.view(H * Dp, -1)
-            parts.append(rw)
-        return torch.cat(parts, 0)
-
-    def _padded_bias(self, Dp: int):
-        if self.bias is None:
-            return None
-        H, D = self.n_heads, self.out_feat
-        bias = self.bias.view(H, D)
-        if Dp != D:
-            bias = torch.cat([bias, bias.new_zeros(H, Dp - D)], 1)
-        return bias.reshape(-1)
+    def _operands(self, Dp: int):
+        """(augmented weight, [e_dim, H] edge score table, head-padded flat bias | None)."""
+        res_w = self.res_fc.weight if isinstance(self.res_fc, nn.Linear) else None
+        out = _FoldFn.apply(self.fc.weight, self.attn_h, self.attn_t, res_w, self.edge_fc.weight, self.attn_e,
+                            self.bias, self.n_heads, self.out_feat, Dp)
+        return out if len(out) == 3 else (out[0], out[1], None)
 
     def fused_params(self, Dp: int):
-        """(augmented weight, [e_dim, H] edge score table, flat bias, PReLU slope | None): the
-        differentiable operands the whole-network node in ``fused.py`` consumes."""
-        H, D = self.n_heads, self.out_feat
-        table = _fold(self.edge_fc.weight, self.attn_e, H, D).t()      # gat.py:297-299 collapsed
+        """(augmented weight, edge score table, flat bias, PReLU slope | None): the differentiable
+        operands the whole-network node in ``fused.py`` consumes."""
+        w_aug, table, bias = self._operands(Dp)
         prelu_w = self.activation.weight if isinstance(self.activation, nn.PReLU) else None
-        return self._augmented_weight(Dp), table, self._padded_bias(Dp), prelu_w
+        return w_aug, table, bias, prelu_w
 
     def forward(self, graph: Graph, feat, get_attention=False):
         if isinstance(feat, tuple):
@@ -261,9 +258,9 @@ class GATConv(nn.Module):
         res_identity = isinstance(self.res_fc, nn.Identity)
         if res_identity and Dp != D:
             raise _lib.MagicHipError("identity residual with a padded head width is not supported")
-        w_aug = self._augmented_weight(Dp)
+        # gat.py:284-299, :323 collapsed into GEMM operands
+        w_aug, table, bias = self._operands(Dp)
         # edge score term: [e_dim, H] table (one-hot attributes) or dense [E, H]
-        table = _fold(self.edge_fc.weight, self.attn_e, H, D).t()      # gat.py:297-299 collapsed
         etype_csc = graph.edge_types_csc()
         if etype_csc is not None:
             edge_term = table.contiguous()
@@ -272,7 +269,6 @@ class GATConv(nn.Module):
         fuse_act = isinstance(self.activation, nn.PReLU) and self.activation.weight.numel() == 1 \
             and self.norm is None and self.concat_out
         prelu_w = self.activation.weight if fuse_act else None
-        bias = self._padded_bias(Dp)
         need_grad = torch.is_grad_enabled()
         cfg = dict(H=H, Dp=Dp, C=C, res_c=C if isinstance(self.res_fc, nn.Linear) else 0,
                    res_identity=res_identity, etype_csc=etype_csc, e_dim=self.edge_feat,
