@@ -169,6 +169,16 @@ int magic_gat_fwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t hea
                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Keep mask of the feature dropout (model/gat.py:283, nn.Dropout(feat_drop) on the layer
+ * input): mask[i] = 1 with probability keep_prob, else 0, from Philox4x32-10 keyed by
+ * (seed, i / 16).  The mask is a function of (seed, i) only.  mask must be 16-byte aligned.
+ * The consumers (magic_proj_fwd x_mask, magic_gat_fwd res_mask, magic_proj_bwd_* masks)
+ * apply it together with the 1/keep_prob scale where the operand is loaded, so the dropped
+ * tensor itself is never written.
+ * ---------------------------------------------------------------------------------- */
+int magic_dropout_mask(int64_t n_elems, float keep_prob, uint64_t seed, uint8_t *mask, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Operands of magic_proj_fwd / magic_gat_fwd built from the layer's parameters in one launch
  * (and the adjoint in one launch), replacing the element-wise chain torch would run for
  * model/gat.py:284-299 and :323:

@@ -42,6 +42,7 @@ SYMBOLS = {
     "magic_proj_bwd_weight_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
     "magic_proj_bwd_weight": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_sz,
                                       c_vp]),
+    "magic_dropout_mask": (c_i32, [c_i64, c_f32, C.c_uint64, c_vp, c_vp]),
     "magic_fold_fwd": (c_i32, [c_i32] * 5 + [c_vp] * 10 + [c_vp]),
     "magic_fold_bwd": (c_i32, [c_i32] * 5 + [c_vp] * 15 + [c_vp]),
     "magic_gat_fwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
@@ -272,6 +273,16 @@ def proj_bwd_weight(dy: torch.Tensor, x: torch.Tensor, x_mask: Optional[torch.Te
                                      _dev(x, torch.float32, "x"), x.stride(0), _dev(x_mask), float(x_scale),
                                      _dev(dw), ws.data_ptr(), ws.numel(), _stream()), "magic_proj_bwd_weight")
     return dw
+
+
+# ------------------------------------------------------------------------------------- dropout
+def dropout_mask(shape, keep_prob: float, seed: int, device) -> torch.Tensor:
+    """uint8 keep mask of the given shape (1 = keep with probability ``keep_prob``)."""
+    lib = load()
+    m = torch.empty(shape, dtype=torch.uint8, device=device)
+    _check(lib.magic_dropout_mask(m.numel(), float(keep_prob), int(seed) & 0xFFFFFFFFFFFFFFFF, _dev(m), _stream()),
+           "magic_dropout_mask")
+    return m
 
 
 # ------------------------------------------------------------------------------------- folds

@@ -21,6 +21,7 @@ from itertools import chain
 import torch
 import torch.nn as nn
 
+from .. import _lib
 from ..graph import Graph
 from ..utils.utils import create_norm
 from .fused import FusedCfg, FusedGMAEFn
@@ -134,8 +135,10 @@ class GMAEModel(nn.Module):
             return [m.to(device=device, dtype=torch.uint8).contiguous() for m in drop_masks], 1.0 / (1.0 - p)
         if not self.training or p == 0.0:
             return [None] * len(widths), 1.0
-        return [torch.empty(n, w, dtype=torch.uint8, device=device).bernoulli_(1.0 - p) for w in widths], \
-            1.0 / (1.0 - p)
+        # one 63-bit seed per mask from torch's CPU generator (reproducible under torch.manual_seed,
+        # no device synchronisation); the masks themselves are drawn on the GPU
+        seeds = torch.randint(0, 2 ** 62, (len(widths),)).tolist()
+        return [_lib.dropout_mask((n, w), 1.0 - p, s, device) for w, s in zip(widths, seeds)], 1.0 / (1.0 - p)
 
     def _fused_cfg(self, g: Graph, drop_masks):
         """Description of the whole encoder -> decoder chain for ``FusedGMAEFn``, or None when a
