@@ -67,21 +67,21 @@ def timed(fn, steps, world):
 
 
 # --------------------------------------------------------------------------- algorithmic bytes
-def layer_dims(n_dim, hidden, layers):
-    """(F, H, D) of every GAT layer of the auto-encoder: encoder layers then the decoder."""
-    dims = [(n_dim if l == 0 else hidden, 4, hidden // 4) for l in range(layers)]
-    dims.append((hidden, 1, n_dim))
-    return dims
-
-
-def kernel_bytes(kind, N, E_seg, H, C):
-    """Algorithmic HBM bytes of one launch (fp32 values, int32 ids, every tensor once)."""
-    if kind == "fwd":      # src id, edge type | gather eh, write a | gather hs row ; ptr, et, out row
-        return E_seg * (8 + 8 * H + 4 * C) + N * (4 + 4 * H + 4 * C)
-    if kind == "bwd_dst":  # src id, a, d_logit out, record | gather hs row ; ptr, d_et, d_out in, d_pre out
-        return E_seg * (8 + 8 * H + 4 * C) + N * (4 + 4 * H + 8 * C)
-    if kind == "bwd_src":  # dst id, position, a & d_logit | gather d_pre row ; ptr, d_eh, d_hs out
-        return E_seg * (12 + 8 * H + 4 * C) + N * (4 + 4 * H + 4 * C)
+def kernel_bytes(kind, N, E_seg, H, C, res):
+    """Algorithmic HBM bytes of one launch of a sparse sweep over the light segments of one layer
+    (fp32 values, int32 ids, every tensor counted once).  ``res``: None | "linear" | "identity"."""
+    if kind == "fwd":
+        # per edge: src id, logit in, attention weight out, gathered hs row
+        # per node: segment pointer, output row, residual row (+ 1-byte keep mask when it is the dropped input)
+        per_node = 4 + 4 * C + (0 if res is None else 4 * C) + (C if res == "identity" else 0)
+        return E_seg * (4 + 8 * H + 4 * C) + N * per_node
+    if kind == "bwd_src":
+        # per edge: dst id, CSC position, gathered gradient row, gathered a, t out
+        # per node: segment pointer, own hs row, d_hs row out
+        return E_seg * (8 + 8 * H + 4 * C) + N * (4 + 8 * C)
+    if kind == "bwd_dst":
+        # per edge: a, t in, d_logit out ; per node: segment pointer, d_et out
+        return E_seg * 12 * H + N * (4 + 4 * H)
     raise ValueError(kind)
 
 
@@ -164,15 +164,17 @@ def main():
         from magic_amd.graph import LIGHT_MAX
         e_light_in = int(deg_in[deg_in <= LIGHT_MAX].sum())
         e_light_out = int(deg_out[deg_out <= LIGHT_MAX].sum())
-        dims = layer_dims(n_dim, hidden, layers)
+
+        from magic_amd.model.gat import _pad_head_dim
+        # (H, C, residual kind) of every GAT layer: encoder layers, then the decoder (head padded)
+        lay = [(4, hidden, "linear" if (n_dim if l == 0 else hidden) != hidden else "identity")
+               for l in range(layers)] + [(1, _pad_head_dim(n_dim), None)]
 
         def avg_bytes(kind, e_seg):
-            return sum(kernel_bytes(kind, n, e_seg, H, H * D) for _, H, D in dims) / len(dims)
+            return sum(kernel_bytes(kind, n, e_seg, H, C, r) for H, C, r in lay) / len(lay)
         algo = {"gat_fwd_light": avg_bytes("fwd", e_light_in),
-                "gat_fwd_heavy_agg": avg_bytes("fwd", E - e_light_in) - sum(
-                    n * (4 + 4 * H + 4 * H * D) for _, H, D in dims) / len(dims),
-                "gat_bwd_dst_light": avg_bytes("bwd_dst", e_light_in),
-                "gat_bwd_src_light": avg_bytes("bwd_src", e_light_out)}
+                "gat_bwd_src_light": avg_bytes("bwd_src", e_light_out),
+                "gat_bwd_dst_light": avg_bytes("bwd_dst", e_light_in)}
         for name, (cnt, tot_ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
             kernels[name] = {"launches": cnt, "avg_us": round(tot_ms / cnt * 1e3, 2),
                              "total_ms_per_step": round(tot_ms / args.steps, 4)}

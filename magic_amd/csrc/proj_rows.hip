@@ -10,7 +10,8 @@
 //  * The 32 x 64 accumulator group goes through a 16-row LDS strip per wave and leaves as whole
 //    rows of float4, so the epilogue operands (residual gradient, dropout mask, concatenation
 //    gradient, activation output) are read and the result written fully coalesced.
-//  * <= 128 VGPRs: 16 waves per CU keep enough loads in flight without software prefetch.
+//  * <= 128 VGPRs (168 for long row segments): 16 (12) waves per CU keep enough loads in flight
+//    without software prefetch.
 #include "proj_common.h"
 
 namespace {
@@ -130,8 +131,12 @@ __device__ __forceinline__ void load_a(const ProjArgs &a, int64_t rc, bool rok, 
     }
 }
 
+// waves per CU the register budget is sized for: 16 (128 VGPRs) for short rows, 12 (168 VGPRs)
+// when the lane's row segment alone takes 32+ registers
+constexpr int rows_max_waves(int kqb) { return kqb >= 8 ? 12 : 16; }
+
 template <int KQB, int NCG, bool EP>
-__global__ __launch_bounds__(1024) void k_proj_rows(ProjArgs a, RowsPlan p) {
+__global__ __launch_bounds__(rows_max_waves(KQB) * 64) void k_proj_rows(ProjArgs a, RowsPlan p) {
     constexpr int KBH = KQB * 4;       // k per lane half and block
     constexpr int KB = KQB * 8;        // k per block
     constexpr int LDO = NCG * 32 + 4;  // strip row stride
@@ -316,12 +321,14 @@ bool choose(const ProjArgs &a, Choice &c) {
     const size_t w_bytes = (size_t)ngroups * ncg * 32 * c.plan.ldw * sizeof(float);
     const size_t strip = (size_t)SR * (ncg * 32 + 4) * sizeof(float);
     // block size that puts the most waves on a CU (160 KB of LDS, 16 waves at <= 128 VGPRs)
+    const int max_waves = rows_max_waves(kqb);
     int best_wpb = 0, best_waves = 0;
-    for (int wpb : {4, 8, 16}) {
+    for (int wpb : {4, 8, 12, 16}) {
+        if (wpb > max_waves) continue;
         const size_t lds = w_bytes + wpb * strip;
         if (lds > 160 * 1024) continue;
         int blocks = (int)((160 * 1024) / lds);
-        if (blocks * wpb > 16) blocks = 16 / wpb;
+        if (blocks * wpb > max_waves) blocks = max_waves / wpb;
         if (blocks * wpb > best_waves) {
             best_waves = blocks * wpb;
             best_wpb = wpb;

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Build profiles/traffic.json and profiles/r01_pmc_summary.txt from two rocprofv3 --pmc passes
+(FETCH_SIZE in one run, WRITE_SIZE in another) over `bench.py --steps 2 --warmup 1`.
+
+HBM bytes per launch = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB.  The factor 2 on the read side is the
+gfx950 correction for 16-byte-per-lane loads (FETCH_SIZE tallies 128-byte requests at 64 bytes);
+it is re-checked on every run against a kernel of this library whose byte count is known exactly:
+gat_bwd_node_adjoint<4,4> streams two [N, 64] fp32 operands with float4 loads and writes one.
+usage: make_traffic.py <pmc_rd_dir> <pmc_wr_dir> <workload> <n_nodes>
+"""
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_summary import summarise  # noqa: E402
+
+BENCH_NAME = {"k_fwd_light": "gat_fwd_light", "k_bwd_src_light": "gat_bwd_src_light",
+              "k_bwd_dst_light": "gat_bwd_dst_light", "k_edge_logits": "gat_edge_logits"}
+
+
+def main():
+    rd_dir, wr_dir, workload, n_nodes = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    rd = {}
+    for f in glob.glob(os.path.join(rd_dir, "**", "*counter_collection.csv"), recursive=True):
+        for k, v in summarise(f).items():
+            if "FETCH_SIZE" in v:
+                rd[k] = v["FETCH_SIZE"]
+    wr = {}
+    for f in glob.glob(os.path.join(wr_dir, "**", "*counter_collection.csv"), recursive=True):
+        for k, v in summarise(f).items():
+            if "WRITE_SIZE" in v:
+                wr[k] = v["WRITE_SIZE"]
+    lines = []
+    cal = rd.get("k_bwd_node_adjoint<4, 4>")
+    if cal:
+        exact = 2 * n_nodes * 64 * 4 / 1024
+        lines.append(f"# calibration: gat_bwd_node_adjoint<4,4> reads exactly {exact:.0f} KiB, FETCH_SIZE reports "
+                     f"{cal:.0f} KiB -> factor {exact / cal:.3f} (the gfx950 factor 2 for 16-byte-per-lane loads)")
+    lines.append(f"{'kernel':44s} {'FETCH KiB':>12s} {'WRITE KiB':>12s} {'HBM MB (2*F+W)':>16s}")
+    traffic = {}
+    for k in sorted(set(rd) | set(wr)):
+        f, w = rd.get(k, 0.0), wr.get(k, 0.0)
+        total = (2 * f + w) * 1024
+        lines.append(f"{k:44s} {f:12.0f} {w:12.0f} {total / 1e6:16.1f}")
+        traffic[k] = total
+    # bench.py reports per name over all layers: launch-weighted mean of the template instances
+    # (three encoder layers <4,LPH> and one decoder layer <1,LPH> per step)
+    out = {}
+    for prefix, name in BENCH_NAME.items():
+        enc = [v for k, v in traffic.items() if k.startswith(prefix + "<4")]
+        dec = [v for k, v in traffic.items() if k.startswith(prefix + "<1")]
+        if enc and dec:
+            out[name] = int((3 * enc[0] + dec[0]) / 4)
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+    path = os.path.join(root, "traffic.json")
+    data = {}
+    if os.path.exists(path):
+        data = json.load(open(path))
+    data[workload] = out
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    open(os.path.join(root, "r01_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:3]))
+    print(out)
+
+
+if __name__ == "__main__":
+    main()
