@@ -5,8 +5,8 @@ single flat fp32 gradient buffer.
 The reference trains in one process (``model/train.py:33-48``, ``train.py:107-118``); the
 gradient payload of its models is tiny (0.24 MB for the entity-level model, 4.9 MB for the
 batch-level one), so the exchange is latency-bound: bucketing or overlapping it with
-backward would only add launches.  Gradients live as views into the flat buffer, so no
-pack / unpack copies surround the collective.
+backward would only add launches.  The ~40 gradient tensors are packed into the flat buffer
+with one ``cat`` and unpacked with one multi-tensor copy; a single-rank run does neither.
 """
 from __future__ import annotations
 
@@ -21,30 +21,34 @@ class FlatGradAllReduce:
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        n = sum(p.numel() for p in self.params)
+        self.sizes = [p.numel() for p in self.params]
         dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=dev)
 
     def zero(self):
-        """Replacement for ``optimizer.zero_grad()`` that keeps the gradient views alive."""
-        self.flat.zero_()
-
-    def check_views(self):
+        """``optimizer.zero_grad(set_to_none=True)``: autograd then stores each gradient instead
+        of accumulating into a zeroed tensor (no launches)."""
         for p in self.params:
-            if p.grad is None or p.grad.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr():
-                raise RuntimeError("a gradient left the flat buffer (zero_grad(set_to_none=True)?); "
-                                   "use FlatGradAllReduce.zero() instead")
+            p.grad = None
+
+    def pack(self) -> torch.Tensor:
+        """All gradients side by side in ``self.flat`` (parameter order; a missing gradient is zero)."""
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        torch.cat(parts, out=self.flat)
+        return self.flat
 
     def allreduce(self):
         """Average the gradients over the ranks: one collective on the whole buffer."""
         if self.world == 1:
             return
+        self.pack()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.div_(self.world)
+        views = self.flat.split(self.sizes)
+        for p, v in zip(self.params, views):
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+        torch._foreach_copy_([p.grad for p in self.params], [v.view_as(p) for p, v in zip(self.params, views)])
 
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None):

@@ -46,9 +46,10 @@ def _dp_worker(rank, world, port, out):
     loss = model.compute_loss(g, perm=perm, pos_idx=torch.arange(n), neg_pairs=neg)
     flat.zero()
     loss.backward()
-    flat.check_views()
-    local = flat.flat.clone()
+    local = flat.pack().clone()
     flat.allreduce()
+    after = torch.cat([p.grad.reshape(-1) for p in flat.params])     # the averaged gradients landed in .grad
+    assert torch.equal(after, flat.flat)
     torch.save({"local": local, "avg": flat.flat.clone(),
                 "w0": torch.cat([p.detach().reshape(-1) for p in model.parameters()])}, f"{out}/dp{rank}.pt")
     dist.destroy_process_group()
