@@ -169,6 +169,18 @@ int magic_gat_fwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t hea
                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Adjoint of a row gather y = x[idx] with repeated indices (model/autoencoder.py:257-258:
+ * enc_rep[sample_src], enc_rep[sample_dst]):  dst[idx[s], :] += src[s, :], idx in [0, n_rows).
+ * (row, position) pairs pass through a stable radix sort over the bits a row index needs; the
+ * first position of every run adds the run in position order: no floating-point atomics,
+ * bitwise reproducible.  idx must not contain out-of-range values (not checked on the device).
+ * ---------------------------------------------------------------------------------- */
+size_t magic_rows_scatter_add_workspace_bytes(int64_t n_src, int64_t n_rows);
+int magic_rows_scatter_add(int64_t n_src, int64_t n_rows, int32_t width, const int64_t *idx,
+                           const float *src, int64_t ld_src, float *dst, int64_t ld_dst,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Keep mask of the feature dropout (model/gat.py:283, nn.Dropout(feat_drop) on the layer
  * input): mask[i] = 1 with probability keep_prob, else 0, from Philox4x32-10 keyed by
  * (seed, i / 16).  The mask is a function of (seed, i) only.  mask must be 16-byte aligned.

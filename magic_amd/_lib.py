@@ -42,6 +42,8 @@ SYMBOLS = {
     "magic_proj_bwd_weight_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
     "magic_proj_bwd_weight": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_sz,
                                       c_vp]),
+    "magic_rows_scatter_add_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "magic_rows_scatter_add": (c_i32, [c_i64, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "magic_dropout_mask": (c_i32, [c_i64, c_f32, C.c_uint64, c_vp, c_vp]),
     "magic_fold_fwd": (c_i32, [c_i32] * 5 + [c_vp] * 10 + [c_vp]),
     "magic_fold_bwd": (c_i32, [c_i32] * 5 + [c_vp] * 15 + [c_vp]),
@@ -273,6 +275,22 @@ def proj_bwd_weight(dy: torch.Tensor, x: torch.Tensor, x_mask: Optional[torch.Te
                                      _dev(x, torch.float32, "x"), x.stride(0), _dev(x_mask), float(x_scale),
                                      _dev(dw), ws.data_ptr(), ws.numel(), _stream()), "magic_proj_bwd_weight")
     return dw
+
+
+# ------------------------------------------------------------------------------------- scatter
+def rows_scatter_add(dst: torch.Tensor, idx: torch.Tensor, src: torch.Tensor):
+    """dst[idx[s]] += src[s] (repeated indices allowed, all in range), bitwise reproducible."""
+    lib = load()
+    assert dst.dim() == 2 and src.dim() == 2 and src.shape[1] == dst.shape[1] and idx.numel() == src.shape[0]
+    assert dst.stride(1) == 1
+    src = _rows(src)
+    idx = idx.to(torch.int64).contiguous()
+    ws = workspace(lib.magic_rows_scatter_add_workspace_bytes(src.shape[0], dst.shape[0]), dst.device)
+    _check(lib.magic_rows_scatter_add(src.shape[0], dst.shape[0], src.shape[1], _dev(idx),
+                                      _dev(src, torch.float32, "src"), src.stride(0),
+                                      _dev(dst, torch.float32, "dst"), dst.stride(0), ws.data_ptr(), ws.numel(),
+                                      _stream()), "magic_rows_scatter_add")
+    return dst
 
 
 # ------------------------------------------------------------------------------------- dropout

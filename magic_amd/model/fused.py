@@ -129,8 +129,8 @@ class FusedGMAEFn(torch.autograd.Function):
         grads[4 * L] = _lib.proj_bwd_weight(d_rep, enc)
         d_enc = _lib.proj_bwd_input(d_rep, w_e2d)[0]                   # [N, L*C]
         if d_samples is not None:
-            # rows used by the edge-reconstruction head (sorted accumulation: reproducible)
-            d_enc.index_put_((sample_idx,), d_samples.contiguous(), accumulate=True)
+            # rows used by the edge-reconstruction head (stable sort + run heads: reproducible)
+            _lib.rows_scatter_add(d_enc, sample_idx, d_samples)
 
         # ---- encoder layers, last to first.  State handed from layer l+1 to layer l: the finished
         # pre-activation gradient d_pre of layer l, the d_y buffer it may live in, and the bias /

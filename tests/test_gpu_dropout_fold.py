@@ -65,3 +65,23 @@ def test_fold_matches_torch(cuda, H, D, Dp, F, e_dim, res, bias):
     for gm, gr in zip(g_mine, g_ref):
         assert gm.shape == gr.shape
         assert torch.allclose(gm, gr, rtol=1e-5, atol=1e-5)
+
+
+def test_rows_scatter_add_with_repeats(cuda):
+    from magic_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    n, s, w = 500, 3000, 192
+    idx = torch.randint(0, n, (s,), generator=g)
+    idx[:40] = 7                                          # a long run of one row
+    src = torch.randn(s, w, generator=g)
+    base = torch.randn(n, w + 8, generator=g)[:, :w]      # strided destination rows
+    want = base.double().clone().index_add_(0, idx, src.double())
+    dst = base.to(cuda)
+    dst = torch.empty(n, w + 8, device=cuda)[:, :w].copy_(dst)
+    out1 = _lib.rows_scatter_add(dst.clone(), idx.to(cuda), src.to(cuda))
+    out2 = _lib.rows_scatter_add(dst.clone(), idx.to(cuda), src.to(cuda))
+    assert torch.equal(out1, out2)
+    assert float((out1.double().cpu() - want).abs().max()) < 1e-4
+    untouched = torch.ones(n, dtype=torch.bool)
+    untouched[idx] = False
+    assert torch.equal(out1[untouched.to(cuda)], dst[untouched.to(cuda)])
