@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
     const int h = g / LPH;
     const bool writer = (g % LPH) == 0;
     const int slot = threadIdx.x / G;
-    for (int u = blockIdx.x * NPB + slot; u < a.N; u += gridDim.x * NPB) {
+    for (int ui = blockIdx.x * NPB + slot; ui < a.N; ui += gridDim.x * NPB) {
+        const int u = ui;  // out-degrees are balanced: natural order keeps the row streams sequential
         const int b = a.pout.ptr[u], e = a.pout.ptr[u + 1];
         if (e - b > a.pout.light_max) continue;
         const float4 hu = ld4_nt(a.hs + (int64_t)u * a.ld_hs + g * 4);
@@ -256,7 +257,8 @@ template <int H> __device__ __forceinline__ void sth(float *p, const HeadVec<H> 
 // one thread per destination node with <= light_max in-edges
 template <int H>
 __global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a, int C) {
-    for (int v = blockIdx.x * 256 + threadIdx.x; v < a.N; v += gridDim.x * 256) {
+    for (int vi = blockIdx.x * 256 + threadIdx.x; vi < a.N; vi += gridDim.x * 256) {
+        const int v = vi;  // one thread per node: neighbouring threads read neighbouring segments
         const int b = a.pin.ptr[v], e = a.pin.ptr[v + 1];
         if (e - b > a.pin.light_max) continue;
         HeadVec<H> delta, det;
@@ -395,7 +397,8 @@ __global__ __launch_bounds__(256) void k_bwd_dst_heavy3(BwdArgs a, int C) {
 // ---- source pass 2: d_eh[u] = sum over out-edges of d_logit -----------------------------------
 template <int H>
 __global__ __launch_bounds__(256) void k_bwd_deh_light(BwdArgs a, int C) {
-    for (int u = blockIdx.x * 256 + threadIdx.x; u < a.N; u += gridDim.x * 256) {
+    for (int ui = blockIdx.x * 256 + threadIdx.x; ui < a.N; ui += gridDim.x * 256) {
+        const int u = ui;
         const int b = a.pout.ptr[u], e = a.pout.ptr[u + 1];
         if (e - b > a.pout.light_max) continue;
         HeadVec<H> s;

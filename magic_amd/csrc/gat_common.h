@@ -20,6 +20,7 @@ struct PlanDev {
     const int32_t *chunk_node;
     const int32_t *chunk_beg;
     const int32_t *chunk_end;
+    const int32_t *order;  // node walk order, or null
 };
 
 inline PlanDev plan_dev(const magic_plan *p) {
@@ -33,6 +34,7 @@ inline PlanDev plan_dev(const magic_plan *p) {
     d.chunk_node = p->chunk_node;
     d.chunk_beg = p->chunk_beg;
     d.chunk_end = p->chunk_end;
+    d.order = p->node_order;
     return d;
 }
 

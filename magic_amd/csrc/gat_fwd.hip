@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
     const int q = g % LPH;
     const int slot = threadIdx.x / G;
     const bool writer = q == 0;
-    for (int v = blockIdx.x * NPB + slot; v < a.N; v += gridDim.x * NPB) {
+    for (int vi = blockIdx.x * NPB + slot; vi < a.N; vi += gridDim.x * NPB) {
+        const int v = a.plan.order ? a.plan.order[vi] : vi;
         const int b = a.plan.ptr[v], e = a.plan.ptr[v + 1];
         const int deg = e - b;
         if (deg > a.plan.light_max) continue;

@@ -44,12 +44,14 @@ class SegmentPlan:
     ``heavy_cptr`` int32 [nh+1]  first chunk of each heavy node
     ``chunk_node`` int32 [nc]    heavy-node slot (index into heavy_node) of each chunk
     ``chunk_beg`` / ``chunk_end`` int32 [nc]  edge range of each chunk
+    ``order``      int32 [N]     node ids by ascending segment length (stable): the walk order of the
+                                 node-driven kernels (equal-length segments share a wavefront)
     """
 
     __slots__ = ("ptr", "heavy_node", "heavy_cptr", "chunk_node", "chunk_beg", "chunk_end",
-                 "n_heavy", "n_chunks")
+                 "n_heavy", "n_chunks", "order")
 
-    def __init__(self, ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end):
+    def __init__(self, ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end, order=None):
         self.ptr = ptr
         self.heavy_node = heavy_node
         self.heavy_cptr = heavy_cptr
@@ -58,10 +60,12 @@ class SegmentPlan:
         self.chunk_end = chunk_end
         self.n_heavy = int(heavy_node.numel())
         self.n_chunks = int(chunk_node.numel())
+        self.order = order
 
     def to(self, device):
         return SegmentPlan(*(t.to(device) for t in (self.ptr, self.heavy_node, self.heavy_cptr,
-                                                     self.chunk_node, self.chunk_beg, self.chunk_end)))
+                                                     self.chunk_node, self.chunk_beg, self.chunk_end)),
+                           order=None if self.order is None else self.order.to(device))
 
 
 def build_segment_plan(ptr: torch.Tensor, light_max: int = LIGHT_MAX, chunk: int = CHUNK) -> SegmentPlan:
@@ -84,8 +88,9 @@ def build_segment_plan(ptr: torch.Tensor, light_max: int = LIGHT_MAX, chunk: int
     beg = ptr64[heavy_node][slot] + within * chunk if nc else slot
     end = torch.minimum(beg + chunk, ptr64[heavy_node + 1][slot]) if nc else slot
     i32 = torch.int32
+    order = torch.sort(deg, stable=True).indices.to(i32)
     return SegmentPlan(ptr.to(i32).contiguous(), heavy_node.to(i32), heavy_cptr.to(i32),
-                       slot.to(i32), beg.to(i32), end.to(i32))
+                       slot.to(i32), beg.to(i32), end.to(i32), order=order)
 
 
 class Structure:
