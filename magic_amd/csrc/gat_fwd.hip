@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
     const int slot = threadIdx.x / G;
     const bool writer = q == 0;
     for (int vi = blockIdx.x * NPB + slot; vi < a.N; vi += gridDim.x * NPB) {
-        const int v = a.plan.order ? a.plan.order[vi] : vi;
+        // walk nodes by segment length when a node row is wide enough to stand alone in memory
+        const int v = (G >= 8 && a.plan.order) ? a.plan.order[vi] : vi;
         const int b = a.plan.ptr[v], e = a.plan.ptr[v + 1];
         const int deg = e - b;
         if (deg > a.plan.light_max) continue;

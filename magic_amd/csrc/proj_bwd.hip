@@ -131,29 +131,38 @@ __global__ __launch_bounds__(256) void k_proj_dw(DwArgs a) {
     }
 }
 
-// dW[i][j] = sum over strips (in strip order, 8 interleaved running sums folded in a fixed
-// order) of the partial tiles; one thread per output element.
+// dW[i][j] = sum over strips of the partial tiles, in a fixed tree: a block takes 32 consecutive
+// tile elements; eight thread groups sum one contiguous eighth of the strips each (strip order,
+// four interleaved running sums), thread group 0 adds the eight results in order.
 template <int MT, int FT>
 __global__ __launch_bounds__(256) void k_proj_dw_reduce(DwArgs a) {
     constexpr int TILE = MT * FT * 16 * 64;
+    __shared__ float part[8][32];
     const int grp = blockIdx.y;
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= TILE) return;
-    const int lane = o & 63, r = (o >> 6) & 15, t = o >> 10;
-    const int mt = t / FT, ft = t % FT;
+    const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int o = blockIdx.x * 32 + e;  // TILE is a multiple of 32
+    const float *p = a.partial + (int64_t)grp * TILE + o;
+    const int64_t stride = (int64_t)gridDim.y * TILE;
+    const int per = (a.n_strips + 7) / 8;
+    const int k0 = sl * per, k1 = min(k0 + per, a.n_strips);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = k0;
+    for (; k + 4 <= k1; k += 4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] += p[(int64_t)(k + u) * stride];
+    for (; k < k1; ++k) s[0] += p[(int64_t)k * stride];
+    part[sl][e] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (sl != 0) return;
+    float t = part[0][e];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += part[q][e];
+    const int lane = o & 63, r = (o >> 6) & 15, tl = o >> 10;
+    const int mt = tl / FT, ft = tl % FT;
     const int m0 = (grp / a.fg) * MT * 32, f0 = (grp % a.fg) * FT * 32;
     const int i = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const int j = f0 + ft * 32 + (lane & 31);
-    if (i >= a.M || j >= a.F) return;
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float *p = a.partial + (int64_t)grp * TILE + o;
-    const int64_t stride = (int64_t)gridDim.y * TILE;
-    int k = 0;
-    for (; k + 8 <= a.n_strips; k += 8)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s[u] += p[(int64_t)(k + u) * stride];
-    for (; k < a.n_strips; ++k) s[0] += p[(int64_t)k * stride];
-    a.dw[(int64_t)i * a.F + j] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    if (i < a.M && j < a.F) a.dw[(int64_t)i * a.F + j] = t;
 }
 
 struct DwPlan {
@@ -164,9 +173,22 @@ struct DwPlan {
 
 DwPlan plan_dw(int64_t n, int M, int F) {
     DwPlan p;
-    int mtiles = (M + 31) / 32, ftiles = (F + 31) / 32;
-    p.ft = ftiles >= 2 ? 2 : 1;
-    p.mt = mtiles >= 3 ? 3 : mtiles;
+    const int mtiles = (M + 31) / 32, ftiles = (F + 31) / 32;
+    // register tile (at most 6 accumulator tiles per wave) that re-reads the least: every M group
+    // streams X once more, every F group streams dY once more
+    static const int cand[][2] = {{3, 2}, {2, 3}, {3, 1}, {1, 3}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
+    double best = -1.0;
+    p.mt = p.ft = 1;
+    for (auto &c : cand) {
+        const int mt = c[0] < mtiles ? c[0] : mtiles, ft = c[1] < ftiles ? c[1] : ftiles;
+        const int mg = (mtiles + mt - 1) / mt, fg = (ftiles + ft - 1) / ft;
+        const double cost = (double)fg * M + (double)mg * F;
+        if (best < 0 || cost < best - 1e-9) {
+            best = cost;
+            p.mt = mt;
+            p.ft = ft;
+        }
+    }
     p.mg = (mtiles + p.mt - 1) / p.mt;
     p.fg = (ftiles + p.ft - 1) / p.ft;
     int groups = p.mg * p.fg;
@@ -175,7 +197,7 @@ DwPlan plan_dw(int64_t n, int M, int F) {
     int64_t waves = (int64_t)strips * 4;
     int64_t rpw = (n + waves - 1) / waves;
     rpw = (rpw + 2 * MAGIC_DW_U - 1) / (2 * MAGIC_DW_U) * (2 * MAGIC_DW_U);  // whole unrolled iterations
-    if (rpw < 8) rpw = 8;
+    if (rpw < 2 * MAGIC_DW_U) rpw = 2 * MAGIC_DW_U;
     p.rows_per_wave = rpw;
     p.n_strips = (int)((n + rpw * 4 - 1) / (rpw * 4));
     if (p.n_strips < 1) p.n_strips = 1;
@@ -193,7 +215,7 @@ template <int MT, int FT> int run_dw(DwArgs &a, const DwPlan &p, hipStream_t str
     }
     dim3 grid(p.n_strips, p.mg * p.fg);
     MAGIC_LAUNCH("proj_bwd_weight_mfma_f32", (k_proj_dw<MT, FT>), grid, 256, sh, stream, a);
-    dim3 rgrid((TILE + 255) / 256, p.mg * p.fg);
+    dim3 rgrid(TILE / 32, p.mg * p.fg);
     MAGIC_LAUNCH("proj_bwd_weight_reduce", (k_proj_dw_reduce<MT, FT>), rgrid, 256, 0, stream, a);
     return magic::launch_status();
 }
@@ -238,6 +260,8 @@ int magic_proj_bwd_weight(int64_t n_rows, int32_t m, int32_t f, const float *dy,
     a.mg = p.mg;
     a.fg = p.fg;
     if (p.mt == 3 && p.ft == 2) return run_dw<3, 2>(a, p, stream);
+    if (p.mt == 2 && p.ft == 3) return run_dw<2, 3>(a, p, stream);
+    if (p.mt == 1 && p.ft == 3) return run_dw<1, 3>(a, p, stream);
     if (p.mt == 3 && p.ft == 1) return run_dw<3, 1>(a, p, stream);
     if (p.mt == 2 && p.ft == 2) return run_dw<2, 2>(a, p, stream);
     if (p.mt == 2 && p.ft == 1) return run_dw<2, 1>(a, p, stream);
