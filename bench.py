@@ -103,7 +103,11 @@ def main():
     from magic_amd.parallel import FlatGradAllReduce, broadcast_parameters
     from magic_amd.utils.utils import set_random_seed
 
-    n, e, n_dim, e_dim, hidden, layers = synth.SHAPES[args.workload]
+    batch_graphs = 1
+    shape_name = args.workload
+    if args.workload == "streamspot_batch":   # one batch-level training step: 12 StreamSpot-sized graphs
+        shape_name, batch_graphs = "streamspot", 12
+    n, e, n_dim, e_dim, hidden, layers = synth.SHAPES[shape_name]
     n, e = max(64, int(n * args.scale)), max(64, int(e * args.scale))
     set_random_seed(0)
     model = GMAEModel(n_dim, e_dim, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(dev)
@@ -112,8 +116,17 @@ def main():
     flat = FlatGradAllReduce(model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4, fused=True)
 
-    g = synth.make_graph(n, e, n_dim, e_dim, seed=1004 + rank, attrs=False).to(dev)
-    g.structure.ensure_csr()
+    if batch_graphs == 1:
+        g = synth.make_graph(n, e, n_dim, e_dim, seed=1004 + rank, attrs=False).to(dev)
+        g.structure.ensure_csr()
+    else:
+        import magic_amd
+        parts = [synth.make_graph(n, e, n_dim, e_dim, seed=1002 + 1000 * rank + i, attrs=False).to(dev)
+                 for i in range(batch_graphs)]
+        for p_ in parts:
+            p_.structure.ensure_csr()
+        g = magic_amd.batch(parts)          # model/train.py:39
+        n = g.num_nodes()
     E = g.num_edges()
     ntype, etype = g.ndata["type"], g.edata["type"]
     e_attr = torch.nn.functional.one_hot(etype, e_dim).float()
@@ -214,7 +227,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"E3-THEIA-shaped full graph per GPU ({args.workload}): N={n} E={E} "
+            "config": {"workload": f"{'E3-THEIA-shaped full graph' if args.workload == 'theia' else args.workload} "
+                                   f"per GPU ({args.workload}): N={n} E={E} "
                                    f"n_dim={n_dim} e_dim={e_dim} hidden={hidden} layers={layers}; "
                                    "compute_loss fwd + bwd + Adam, dropout on, mask perms and sampled pairs "
                                    "pre-generated", "parallelism": f"dp{world} (one graph per rank, "

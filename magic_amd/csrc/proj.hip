@@ -17,7 +17,7 @@
 #include "proj_common.h"
 
 namespace magic {
-int proj_rows_try(const ProjArgs &a, int64_t *n_part, bool dry_run, hipStream_t stream);
+int proj_rows_try(const ProjArgs &a, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream);
 }
 
 namespace {
@@ -319,15 +319,15 @@ __global__ __launch_bounds__(256, stream_waves(NCT, KCH, MODE)) void k_proj_stre
 
 // fixed-order reduction of the per-wave partial rows: block c < C sums column c, block C the
 // PReLU partials (256 threads take rows round robin, then a tree)
-__global__ __launch_bounds__(256) void k_proj_sums(const float *part_col, const float *part_prelu, int n_part, int C,
-                                                   float *col_sum, float *prelu_grad) {
+__global__ __launch_bounds__(256) void k_proj_sums(const float *part_col, const float *part_prelu, int n_part,
+                                                   int n_prelu, int C, float *col_sum, float *prelu_grad) {
     __shared__ float red[256];
     const int c = blockIdx.x;
     float t = 0.f;
     if (c < C) {
         for (int k = threadIdx.x; k < n_part; k += 256) t += part_col[(int64_t)k * C + c];
     } else {
-        for (int k = threadIdx.x; k < n_part; k += 256) t += part_prelu[k];
+        for (int k = threadIdx.x; k < n_prelu; k += 256) t += part_prelu[k];
     }
     red[threadIdx.x] = t;
     __syncthreads();
@@ -458,7 +458,7 @@ int64_t n_partials(const ProjArgs &a, int nct) {
 int dispatch(const ProjArgs &a0, hipStream_t stream) {
     ProjArgs a = a0;
     a.col0 = 0;
-    const int st_rows = magic::proj_rows_try(a, nullptr, false, stream);
+    const int st_rows = magic::proj_rows_try(a, nullptr, nullptr, false, stream);
     if (st_rows != MAGIC_ERR_UNSUPPORTED) return st_rows;
     const int tiles = (a.M + 31) / 32;
     if (tiles <= 10) {
@@ -536,7 +536,8 @@ size_t magic_proj_bwd_input_workspace_bytes(int64_t n_rows, int32_t k_dim, int32
     // upper bound over the kernel variants: one partial row per wave of the grid
     int64_t np = ((n_rows + BM - 1) / BM) * 4;
     if (np < 4096) np = 4096;
-    return magic::align_up((size_t)np * out_dim * sizeof(float)) + magic::align_up((size_t)np * sizeof(float)) + 256;
+    const size_t windows = (size_t)(out_dim + 63) / 64;  // part_prelu holds one row per 64-column window
+    return magic::align_up((size_t)np * out_dim * sizeof(float)) + magic::align_up((size_t)np * windows * sizeof(float)) + 256;
 }
 
 int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim, const float *dy, int64_t ld_dy,
@@ -576,21 +577,25 @@ int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim, const f
         sums = ep->col_sum != nullptr || ep->prelu_grad != nullptr;
     }
     int64_t np = 0;
+    int n_win = 1;
     if (sums) {
         const int tiles = (out_dim + 31) / 32;
-        if (tiles > 10) return MAGIC_ERR_UNSUPPORTED;  // column sums need a single launch
         a.part_col = static_cast<float *>(workspace);  // provisional: the kernel choice looks at it
-        if (magic::proj_rows_try(a, &np, true, stream) != MAGIC_OK) np = n_partials(a, tiles);
+        if (magic::proj_rows_try(a, &np, &n_win, true, stream) != MAGIC_OK) {
+            if (tiles > 10) return MAGIC_ERR_UNSUPPORTED;  // column sums need a single launch there
+            np = n_partials(a, tiles);
+            n_win = 1;
+        }
         magic::Arena ar(workspace, workspace_bytes);
         a.part_col = ar.take<float>((size_t)np * out_dim);
-        a.part_prelu = ar.take<float>((size_t)np);
+        a.part_prelu = ar.take<float>((size_t)np * n_win);
         if (!ar.ok() || !a.part_col || !a.part_prelu) return MAGIC_ERR_WORKSPACE;
     }
     int st = dispatch(a, stream);
     if (st != MAGIC_OK) return st;
     if (sums) {
         MAGIC_LAUNCH("proj_bwd_input_sums", k_proj_sums, out_dim + 1, 256, 0, stream, a.part_col, a.part_prelu, (int)np,
-                     out_dim, ep->col_sum, ep->prelu_grad);
+                     (int)np * n_win, out_dim, ep->col_sum, ep->prelu_grad);
     }
     return magic::launch_status();
 }

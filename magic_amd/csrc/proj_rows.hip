@@ -174,7 +174,7 @@ __global__ __launch_bounds__(rows_max_waves(KQB) * 64) void k_proj_rows(ProjArgs
 
         // one column group's accumulators through the strip, out as rows of float4
         auto store_group = [&](int g) {
-            const int gc = g * NCG * 32 + (lane % C4) * 4;  // this lane's columns in every strip row
+            const int gc = a.col0 + g * NCG * 32 + (lane % C4) * 4;  // this lane's columns in every strip row
             Dst d;
             if (!EP) d = route(a, gc);
 #pragma unroll
@@ -259,7 +259,8 @@ __global__ __launch_bounds__(rows_max_waves(KQB) * 64) void k_proj_rows(ProjArgs
             cs4.w += __shfl_xor(cs4.w, off, 64);
         }
         const int64_t prow = (int64_t)blockIdx.x * p.wpb + wave;
-        if (lane < C4 && lane * 4 < a.C) *reinterpret_cast<float4 *>(a.part_col + prow * a.C + lane * 4) = cs4;
+        if (lane < C4 && a.col0 + lane * 4 < a.C)
+            *reinterpret_cast<float4 *>(a.part_col + prow * a.C + a.col0 + lane * 4) = cs4;
         if (a.part_prelu) {
             float s = dprelu;
 #pragma unroll
@@ -279,14 +280,16 @@ struct Choice {
 // float4 per lane half and K block the kernel is instantiated for
 const int kKqb[] = {1, 2, 3, 4, 6, 8, 9, 12};
 
-bool choose(const ProjArgs &a, Choice &c) {
-    if (a.col0 != 0 || a.n <= 0) return false;
+// `mw`: number of output columns this launch covers, starting at a.col0 (the whole M, or one
+// 64-column window of a wide epilogue launch)
+bool choose(const ProjArgs &a, int mw, Choice &c) {
+    if (a.n <= 0) return false;
     const bool vec = (a.F & 3) == 0 && aligned16(a.x, a.ld_x) && (!a.x_mask || (uintptr_t)a.x_mask % 4 == 0);
     if (!vec && a.F > 24) return false;  // element-wise operand loads exist for short rows only
     const bool ep = has_epilogue(a);
     if (ep) {
         // the vectorised epilogue: one column group of whole tiles, float4-aligned operands
-        if (a.M != a.C || (a.C != 32 && a.C != 64)) return false;
+        if (a.M != a.C || (mw != 32 && mw != 64) || a.col0 + mw > a.C) return false;
         if (!aligned16(a.hs, a.ld_hs)) return false;
         if (a.add && !aligned16(a.add, a.ld_add)) return false;
         if (a.add2 && !aligned16(a.add2, a.ld_add2)) return false;
@@ -309,7 +312,7 @@ bool choose(const ProjArgs &a, Choice &c) {
             break;
         }
     if (!kqb) return false;
-    const int tiles = (a.M + 31) / 32;
+    const int tiles = (mw + 31) / 32;
     const int ncg = tiles >= 2 ? 2 : 1;
     const int ngroups = (tiles + ncg - 1) / ncg;
     if (nkb > 1 && ngroups > 1) return false;
@@ -367,25 +370,43 @@ namespace magic {
 
 // Runs the projection on the row-owner kernel when the shape and the operand alignment allow it.
 // Returns MAGIC_ERR_UNSUPPORTED otherwise (the caller falls back to the LDS-staged kernels).
-// `n_part` receives the number of partial-sum rows the launch writes (one per wave of the grid);
-// with `dry_run` nothing is launched.
-int proj_rows_try(const ProjArgs &a, int64_t *n_part, bool dry_run, hipStream_t stream) {
-    Choice c;
-    if (!choose(a, c)) return MAGIC_ERR_UNSUPPORTED;
-    if (n_part) *n_part = (int64_t)c.grid * c.plan.wpb;
-    if (dry_run) return MAGIC_OK;
+// An epilogue launch wider than 64 columns runs as 64-column windows (each streams dY again:
+// those shapes are MFMA-bound, not HBM-bound).  `n_part` receives the number of partial-sum rows
+// one window writes (one per wave of the grid), `n_win` the number of windows: part_col is
+// [n_part, C], part_prelu [n_win, n_part].  With `dry_run` nothing is launched.
+int proj_rows_try(const ProjArgs &a0, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream) {
+    ProjArgs a = a0;
+    a.col0 = 0;
     const bool ep = has_epilogue(a);
-    switch (c.kqb) {
-        case 1: return launch_kq<1>(a, c, ep, stream);
-        case 2: return launch_kq<2>(a, c, ep, stream);
-        case 3: return launch_kq<3>(a, c, ep, stream);
-        case 4: return launch_kq<4>(a, c, ep, stream);
-        case 6: return launch_kq<6>(a, c, ep, stream);
-        case 8: return launch_kq<8>(a, c, ep, stream);
-        case 9: return launch_kq<9>(a, c, ep, stream);
-        case 12: return launch_kq<12>(a, c, ep, stream);
-        default: return MAGIC_ERR_UNSUPPORTED;
+    int windows = 1, mw = a.M;
+    if (ep && a.M == a.C && a.C > 64) {
+        if (a.C % 64) return MAGIC_ERR_UNSUPPORTED;
+        windows = a.C / 64;
+        mw = 64;
     }
+    Choice c;
+    if (!choose(a, mw, c)) return MAGIC_ERR_UNSUPPORTED;
+    if (n_part) *n_part = (int64_t)c.grid * c.plan.wpb;
+    if (n_win) *n_win = windows;
+    if (dry_run) return MAGIC_OK;
+    for (int wdx = 0; wdx < windows; ++wdx) {
+        a.col0 = wdx * mw;
+        if (a0.part_prelu) a.part_prelu = a0.part_prelu + (int64_t)wdx * c.grid * c.plan.wpb;
+        int st;
+        switch (c.kqb) {
+            case 1: st = launch_kq<1>(a, c, ep, stream); break;
+            case 2: st = launch_kq<2>(a, c, ep, stream); break;
+            case 3: st = launch_kq<3>(a, c, ep, stream); break;
+            case 4: st = launch_kq<4>(a, c, ep, stream); break;
+            case 6: st = launch_kq<6>(a, c, ep, stream); break;
+            case 8: st = launch_kq<8>(a, c, ep, stream); break;
+            case 9: st = launch_kq<9>(a, c, ep, stream); break;
+            case 12: st = launch_kq<12>(a, c, ep, stream); break;
+            default: return MAGIC_ERR_UNSUPPORTED;
+        }
+        if (st != MAGIC_OK) return st;
+    }
+    return MAGIC_OK;
 }
 
 }  // namespace magic
