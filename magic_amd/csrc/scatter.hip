@@ -16,17 +16,15 @@ __global__ __launch_bounds__(256) void k_scatter_keys(int64_t n, const int64_t *
     }
 }
 
-// One 256-thread block per run head.  The run is cut into four contiguous parts, one per wave;
-// every lane owns columns lane, lane+64, ... and adds its part's rows in position order (four
-// loads in flight); the four partial sums are combined in wave order.  The summation tree
-// depends only on the run length.
+// One 256-thread block per (position, 256-column slab).  The block of a run head adds the run's
+// rows in position order, one column per thread, four loads in flight; every other block exits.
+// The summation order depends only on the run.
 __global__ __launch_bounds__(256) void k_scatter_add(int n, int width, const int32_t *key, const int32_t *pos,
                                                      const float *src, int64_t ld_src, float *dst, int64_t ld_dst) {
-    __shared__ float part[3][64];
     const int i = blockIdx.x;
     const int r = key[i];
     if (i > 0 && key[i - 1] == r) return;  // not the head of its run
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     int end = i + 1;  // end of the run: 64 candidates per step (every wave scans for itself)
     for (;;) {
         const int j = end + lane;
@@ -38,26 +36,17 @@ __global__ __launch_bounds__(256) void k_scatter_add(int n, int width, const int
         end += __ffsll((long long)~same) - 1;
         break;
     }
-    const int len = end - i, per = (len + 3) / 4;
-    const int b = i + wave * per, e = min(b + per, end);
-    for (int c0 = 0; c0 < width; c0 += 64) {
-        const int c = c0 + lane;
-        float acc = 0.f;
-        if (c < width) {
-            int j = b;
-            for (; j + 4 <= e; j += 4) {
-                const float v0 = src[(int64_t)pos[j] * ld_src + c], v1 = src[(int64_t)pos[j + 1] * ld_src + c],
-                            v2 = src[(int64_t)pos[j + 2] * ld_src + c], v3 = src[(int64_t)pos[j + 3] * ld_src + c];
-                acc = (((acc + v0) + v1) + v2) + v3;
-            }
-            for (; j < e; ++j) acc += src[(int64_t)pos[j] * ld_src + c];
-        }
-        __syncthreads();
-        if (wave > 0) part[wave - 1][lane] = acc;
-        __syncthreads();
-        if (wave == 0 && c < width)
-            dst[(int64_t)r * ld_dst + c] = dst[(int64_t)r * ld_dst + c] + (((acc + part[0][lane]) + part[1][lane]) + part[2][lane]);
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= width) return;
+    float acc = dst[(int64_t)r * ld_dst + c];
+    int j = i;
+    for (; j + 4 <= end; j += 4) {
+        const float v0 = src[(int64_t)pos[j] * ld_src + c], v1 = src[(int64_t)pos[j + 1] * ld_src + c],
+                    v2 = src[(int64_t)pos[j + 2] * ld_src + c], v3 = src[(int64_t)pos[j + 3] * ld_src + c];
+        acc = (((acc + v0) + v1) + v2) + v3;
     }
+    for (; j < end; ++j) acc += src[(int64_t)pos[j] * ld_src + c];
+    dst[(int64_t)r * ld_dst + c] = acc;
 }
 
 int bits_for(int64_t n) {
@@ -105,7 +94,7 @@ int magic_rows_scatter_add(int64_t n_src, int64_t n_rows, int32_t width, const i
                                                stream) != hipSuccess)
             return MAGIC_ERR_RUNTIME;
     }
-    MAGIC_LAUNCH("rows_scatter_add", k_scatter_add, (unsigned)n_src, 256, 0, stream, (int)n_src, width, key_s, pos_s, src,
+    MAGIC_LAUNCH("rows_scatter_add", k_scatter_add, dim3((unsigned)n_src, (unsigned)((width + 255) / 256)), 256, 0, stream, (int)n_src, width, key_s, pos_s, src,
                  ld_src, dst, ld_dst);
     return magic::launch_status();
 }
