@@ -212,3 +212,46 @@ def test_embed_matches_oracle_and_is_deterministic(cuda):
         e2 = mine.embed(g)
     assert rel_err(e1, eo) < 1e-4
     assert torch.equal(e1, e2)   # no atomics anywhere: bitwise reproducible
+
+
+def test_batch_level_train_loop(cuda):
+    """``batch_level_train`` (model/train.py:18-48 of the reference) on a handful of small graphs:
+    the loop runs on batched graphs, moves the parameters and lowers the loss."""
+    import random as pyrandom
+    from magic_amd import synth
+    from magic_amd.model.autoencoder import GMAEModel
+    from magic_amd.model.train import batch_level_train
+    n_dim, e_dim = 8, 20
+    torch.manual_seed(0)
+    pyrandom.seed(0)
+    graphs = [(synth.make_graph(300 + 20 * i, 12000 + 100 * i, n_dim, e_dim, seed=70 + i, attrs=False), 0)
+              for i in range(6)]
+    for g, _ in graphs:
+        g.to(cuda).structure.ensure_csr()
+    graphs = [(g.to(cuda), y) for g, y in graphs]
+    model = GMAEModel(n_dim, e_dim, 64, 2, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(cuda)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4)
+    loader = [[0, 1, 2], [3, 4, 5]]
+
+    def epoch_loss():
+        model.eval()
+        tot = 0.0
+        gen = torch.Generator().manual_seed(1)
+        from magic_amd.utils.loaddata import transform_graph
+        import magic_amd
+        for b in loader:
+            bg = magic_amd.batch([transform_graph(graphs[i][0], n_dim, e_dim) for i in b])
+            n, e = bg.num_nodes(), bg.num_edges()
+            with torch.enable_grad():
+                tot += float(model.compute_loss(bg, perm=torch.randperm(n, generator=gen).to(cuda),
+                                                pos_idx=torch.randint(0, e, (n,), generator=gen),
+                                                neg_pairs=(torch.randint(0, n, (n,), generator=gen),
+                                                           torch.randint(0, n, (n,), generator=gen))))
+        return tot
+
+    before = epoch_loss()
+    w0 = model.encoder.gats[0].fc.weight.detach().clone()
+    batch_level_train(model, graphs, loader, opt, 8, cuda, n_dim, e_dim, progress=False)
+    after = epoch_loss()
+    assert not torch.equal(w0, model.encoder.gats[0].fc.weight)
+    assert after < before, (before, after)
