@@ -85,7 +85,7 @@ typedef struct magic_plan {
     const int32_t *chunk_node; /* [n_chunks] heavy slot (index into heavy_node) */
     const int32_t *chunk_beg;  /* [n_chunks] first edge of the chunk */
     const int32_t *chunk_end;  /* [n_chunks] one past the last edge */
-    const int32_t *node_order; /* [N] node ids by ascending segment length (stable), or NULL for 0..N-1:
+    const int32_t *node_order; /* [N] node ids by ascending segment-length class (stable), or NULL for 0..N-1:
                                   the node-driven kernels walk nodes in this order so that the lane groups
                                   of one wavefront hold segments of equal length (results do not depend on it) */
 } magic_plan;

@@ -136,30 +136,31 @@ template <int H, int LPH>
 __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
     constexpr int G = H * LPH;
     constexpr int NPB = 256 / G;
+    constexpr int SB = 4;  // edges per batch (8 measured the same: the sweep is bandwidth-bound)
     const int g = threadIdx.x % G;
     const int h = g / LPH;
     const bool writer = (g % LPH) == 0;
     const int slot = threadIdx.x / G;
     for (int ui = blockIdx.x * NPB + slot; ui < a.N; ui += gridDim.x * NPB) {
-        const int u = ui;  // out-degrees are balanced: natural order keeps the row streams sequential
+        const int u = (G >= 8 && a.pout.order) ? a.pout.order[ui] : ui;
         const int b = a.pout.ptr[u], e = a.pout.ptr[u + 1];
         if (e - b > a.pout.light_max) continue;
         const float4 hu = ld4_nt(a.hs + (int64_t)u * a.ld_hs + g * 4);
         float4 acc = f4zero();
-        for (int j = b; j < e; j += 4) {  // batches of 4 with clamped indices: loads stay unconditional
-            int pos[4];
-            float4 r[4];
-            float w[4];
+        for (int j = b; j < e; j += SB) {  // batches with clamped indices: loads stay unconditional
+            int pos[SB];
+            float4 r[SB];
+            float w[SB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < SB; ++k) {
                 const int jj = min(j + k, e - 1);
                 pos[k] = a.out_pos[jj];
                 r[k] = ld4(a.d_pre + (int64_t)a.out_dst[jj] * a.ld_dpre + g * 4);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] = fabsf(a.attn[(int64_t)pos[k] * H + h]);
+            for (int k = 0; k < SB; ++k) w[k] = fabsf(a.attn[(int64_t)pos[k] * H + h]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < SB; ++k) {
                 const float tt = head_sum<LPH>(dot4(r[k], hu));
                 if (j + k < e) {
                     if (writer) a.t[(int64_t)pos[k] * H + h] = tt;

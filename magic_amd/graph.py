@@ -44,8 +44,8 @@ class SegmentPlan:
     ``heavy_cptr`` int32 [nh+1]  first chunk of each heavy node
     ``chunk_node`` int32 [nc]    heavy-node slot (index into heavy_node) of each chunk
     ``chunk_beg`` / ``chunk_end`` int32 [nc]  edge range of each chunk
-    ``order``      int32 [N]     node ids by ascending segment length (stable): the walk order of the
-                                 node-driven kernels (equal-length segments share a wavefront)
+    ``order``      int32 [N]     node ids by ascending segment-length class (``walk_class``, stable):
+                                 the walk order of the node-driven kernels
     """
 
     __slots__ = ("ptr", "heavy_node", "heavy_cptr", "chunk_node", "chunk_beg", "chunk_end",
@@ -68,6 +68,17 @@ class SegmentPlan:
                            order=None if self.order is None else self.order.to(device))
 
 
+def walk_class(deg: torch.Tensor) -> torch.Tensor:
+    """Length class of a segment for the walk order of the node-driven kernels: 0 (empty), 1 (1-4
+    edges: the single-batch fast path), then one class per power of two.  Coarse classes keep
+    neighbouring node ids next to each other inside a class (their segments share cache lines)
+    while the lane groups of one wavefront still run the same code path for about as long."""
+    d = deg.clamp(min=0).to(torch.float64)
+    return torch.where(deg <= 0, torch.zeros_like(deg),
+                       torch.where(deg <= 4, torch.ones_like(deg),
+                                   torch.ceil(torch.log2(d.clamp(min=1))).to(deg.dtype)))
+
+
 def build_segment_plan(ptr: torch.Tensor, light_max: int = LIGHT_MAX, chunk: int = CHUNK) -> SegmentPlan:
     """Cut every segment longer than ``light_max`` into chunks of ``chunk`` edges.
 
@@ -88,7 +99,7 @@ def build_segment_plan(ptr: torch.Tensor, light_max: int = LIGHT_MAX, chunk: int
     beg = ptr64[heavy_node][slot] + within * chunk if nc else slot
     end = torch.minimum(beg + chunk, ptr64[heavy_node + 1][slot]) if nc else slot
     i32 = torch.int32
-    order = torch.sort(deg, stable=True).indices.to(i32)
+    order = torch.sort(walk_class(deg), stable=True).indices.to(i32)
     return SegmentPlan(ptr.to(i32).contiguous(), heavy_node.to(i32), heavy_cptr.to(i32),
                        slot.to(i32), beg.to(i32), end.to(i32), order=order)
 

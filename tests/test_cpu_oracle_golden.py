@@ -206,8 +206,10 @@ def test_segment_plan_matches_oracle():
     assert np.array_equal(plan.chunk_node.numpy(), cn)
     assert np.array_equal(plan.chunk_beg.numpy(), cb) and np.array_equal(plan.chunk_end.numpy(), ce)
     assert hv.size >= 1 and (ce - cb).max() == CHUNK
-    # walk order: nodes by ascending segment length, ties by ascending id
-    assert np.array_equal(plan.order.numpy(), np.argsort(np.diff(ptr), kind="stable").astype(np.int32))
+    # walk order: nodes by ascending length class (0 | 1-4 | (4,8] | (8,16] | ...), ties by ascending id
+    deg = np.diff(ptr)
+    cls = np.where(deg <= 0, 0, np.where(deg <= 4, 1, np.ceil(np.log2(np.maximum(deg, 1))))).astype(np.int64)
+    assert np.array_equal(plan.order.numpy(), np.argsort(cls, kind="stable").astype(np.int32))
     empty = build_segment_plan(torch.zeros(5, dtype=torch.int32))
     assert empty.n_heavy == 0 and empty.n_chunks == 0
 
