@@ -120,15 +120,20 @@ def _model_pair(n_dim, e_dim, hidden, layers, dev, seed=0, alias=True):
     ((12, 9, 128, 2), False, "drop"),
     ((5, 17, 64, 3), True, "negslope"),      # PReLU slopes <= 0: pre-activation must come from storage
     ((6, 7, 32, 2), True, "drop"),
+    ((5, 17, 64, 3), True, "tiny"),          # 33 nodes / 70 edges: ragged last row tile everywhere
 ])
 def test_autoencoder_loss_and_grads(cuda, shape, alias, mode):
     n_dim, e_dim, hidden, layers = shape
     n, e = 700, 3000
-    src, dst, ntype, etype = small_graph(n, e, n_dim, e_dim, seed=21, hub_deg=200, hub_out=150)
+    if mode == "tiny":
+        n, e = 33, 70
+        src, dst, ntype, etype = small_graph(n, e, n_dim, e_dim, seed=22)
+    else:
+        src, dst, ntype, etype = small_graph(n, e, n_dim, e_dim, seed=21, hub_deg=200, hub_out=150)
     ref, mine = _model_pair(n_dim, e_dim, hidden, layers, cuda, alias=alias)
     gen = torch.Generator().manual_seed(5)
     drop_o = drop_m = None
-    if mode == "drop":
+    if mode in ("drop", "tiny"):
         ref.train()
         mine.train()
         widths = [n_dim] + [hidden] * (layers - 1) + [hidden]
@@ -255,3 +260,23 @@ def test_batch_level_train_loop(cuda):
     after = epoch_loss()
     assert not torch.equal(w0, model.encoder.gats[0].fc.weight)
     assert after < before, (before, after)
+
+
+def test_embed_on_edgeless_graph(cuda):
+    """No edges at all: every node is 'bias + residual' through the layers (zero in-degree is allowed,
+    model/gat.py:180 never checks the flag)."""
+    n_dim, e_dim, n = 5, 17, 50
+    ref, mine = _model_pair(n_dim, e_dim, 64, 3, cuda, seed=2)
+    ref.eval()
+    mine.eval()
+    src = np.zeros(0, dtype=np.int64)
+    rng = np.random.default_rng(0)
+    ntype = rng.integers(0, n_dim, n)
+    etype = np.zeros(0, dtype=np.int64)
+    og = to_ograph(src, src, n, ntype, etype, n_dim, e_dim, torch.float64)
+    g = to_graph(src, src, n, ntype, etype, n_dim, e_dim, cuda)
+    with torch.no_grad():
+        eo = copy.deepcopy(ref).double().embed(og)
+        em = mine.embed(g)
+    assert em.shape == (n, 64)
+    assert rel_err(em, eo) < 1e-5
