@@ -1,12 +1,20 @@
-// Row-owner variant of the dense node projection (same arithmetic as proj.hip: fp32 MFMA
-// 32x32x2, every product exact, sum order fixed), laid out for memory-level parallelism:
+// Row-owner variant of the dense node projection, laid out for memory-level parallelism.
+//
+// Arithmetic: fp32 operands are split into three bf16 pieces each (a = a1 + a2 + a3 exactly: 8 + 8
+// + 8 significant bits, round-to-nearest at every step) and the six leading cross products
+// a1b1, a1b2, a2b1, a2b2, a1b3, a3b1 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Every
+// kept product is exact; the dropped ones (a2b3, a3b2, a3b3) are below 2^-23 |a||b|, the size of
+// one fp32 rounding.  Six bf16 MFMAs cover 16 k in 6 x 32 cycles where the fp32 MFMA needs
+// 8 x 64: the matrix pipe is busy 2.7x less for fp32-grade results (measured against the fp32
+// MFMA kernels of proj.hip in the tests).  Sum order is fixed, results are reproducible.
+//
 //
 //  * A operand straight from HBM: lane l owns row (l & 31) of the wave's 32-row tile and the
 //    half (l >> 5) of every K block -- KQB consecutive float4 of its own row, which are exactly the
-//    per-lane A fragments of KQB*4 MFMA steps (the K index inside a block is permuted so that a
-//    lane half owns contiguous k; the weight fragments use the same permutation).  No staging of
-//    X, no barrier, no padding of K beyond a multiple of 8.
-//  * W (zero padded) stays in LDS for the life of the block.
+//    per-lane A fragments of KQB/2 MFMA steps of 16 k (the K index inside a block is permuted so
+//    that a lane half owns contiguous k; the weight fragments use the same permutation).  No
+//    staging of X, no barrier, K padded to a multiple of 16 only.
+//  * W (zero padded, already split into its three bf16 planes) stays in LDS for the life of the block.
 //  * The 32 x 64 accumulator group goes through a 16-row LDS strip per wave and leaves as whole
 //    rows of float4, so the epilogue operands (residual gradient, dropout mask, concatenation
 //    gradient, activation output) are read and the result written fully coalesced.
@@ -19,7 +27,7 @@ namespace {
 struct RowsPlan {
     int nkb;      // K blocks of KQB*8
     int ngroups;  // column groups of NCG*32
-    int ldw;      // floats per staged weight row (nkb*KQB*8 + 4)
+    int ldw;      // bf16 elements per staged weight row (nkb*KQB*8 + 8)
     int wpb;      // waves per block
 };
 
@@ -66,14 +74,40 @@ __device__ __forceinline__ void route_store_elems(const ProjArgs &a, float4 v, i
     }
 }
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// v = h1 + h2 + h3 exactly (round-to-nearest pieces, v_cvt_pk_bf16_f32), two values at a time
+__device__ __forceinline__ void split2(f32x2_t v, bf16x2_t &h1, bf16x2_t &h2, bf16x2_t &h3) {
+    h1 = __builtin_convertvector(v, bf16x2_t);
+    const f32x2_t r1 = v - __builtin_convertvector(h1, f32x2_t);
+    h2 = __builtin_convertvector(r1, bf16x2_t);
+    const f32x2_t r2 = r1 - __builtin_convertvector(h2, f32x2_t);
+    h3 = __builtin_convertvector(r2, bf16x2_t);
+}
+
+// eight consecutive k of a lane's row -> the three bf16 operand vectors of one MFMA step
+__device__ __forceinline__ void split8(float4 lo, float4 hi, bf16x8_t &p1, bf16x8_t &p2, bf16x8_t &p3) {
+    const f32x2_t v[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bf16x2_t h1, h2, h3;
+        split2(v[j], h1, h2, h3);
+        p1[2 * j] = h1[0], p1[2 * j + 1] = h1[1];
+        p2[2 * j] = h2[0], p2[2 * j + 1] = h2[1];
+        p3[2 * j] = h3[0], p3[2 * j + 1] = h3[1];
+    }
+}
+
 // The lane's KQB float4 of one K block of its own row (k in [k0, k0 + 4*KQB)), dropout mask applied.
 // Loads are unconditional (clamped row `rc`, clamped column): rows past the end and columns past F
 // come back as zeros.  `vec`: rows are 16-byte aligned and F % 4 == 0; the element-wise form only
-// exists for short rows (KQB <= 3).
+// exists for short rows (KQB <= 4).
 template <int KQB>
 __device__ __forceinline__ void load_a(const ProjArgs &a, int64_t rc, bool rok, int k0, bool vec, float4 (&af)[KQB]) {
     uint32_t mw[KQB];
-    if (KQB > 3 || vec) {
+    if (KQB > 4 || vec) {
         const float *px = a.x + rc * a.ld_x;
 #pragma unroll
         for (int q = 0; q < KQB; ++q) {
@@ -145,14 +179,26 @@ __global__ __launch_bounds__(rows_max_waves(KQB) * 64) void k_proj_rows(ProjArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, hf = lane >> 5;
     const int mpad = p.ngroups * NCG * 32;
-    float *wl = sm;
-    float *os = sm + (size_t)mpad * p.ldw + wave * (SR * LDO);
-    {  // stage the zero-padded weight: wl[col][k]
+    // three bf16 planes of the weight, wb[plane][col][k], then one fp32 strip per wave
+    __bf16 *wb = reinterpret_cast<__bf16 *>(sm);
+    const int plane = mpad * p.ldw;  // bf16 elements per plane (a multiple of 8)
+    float *os = sm + (size_t)3 * plane / 2 + wave * (SR * LDO);
+    {  // stage the zero-padded weight
         const bool wvec = (a.F % 4 == 0) && a.w_cs == 1 && (a.w_rs % 4 == 0) && ((uintptr_t)a.w % 16 == 0);
-        const int kq = (p.ldw - 4) / 4;
+        const int kq = (p.ldw - 8) / 4;
         for (int idx = tid; idx < mpad * kq; idx += blockDim.x) {
             const int r = idx / kq, c4 = (idx % kq) * 4;
-            *reinterpret_cast<float4 *>(wl + r * p.ldw + c4) = load_w4(a, r, c4, wvec);
+            const float4 v = load_w4(a, r, c4, wvec);
+            bf16x2_t h1[2], h2[2], h3[2];
+            split2(f32x2_t{v.x, v.y}, h1[0], h2[0], h3[0]);
+            split2(f32x2_t{v.z, v.w}, h1[1], h2[1], h3[1]);
+            __bf16 *d = wb + r * p.ldw + c4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                d[2 * j] = h1[j][0], d[2 * j + 1] = h1[j][1];
+                d[plane + 2 * j] = h2[j][0], d[plane + 2 * j + 1] = h2[j][1];
+                d[2 * plane + 2 * j] = h3[j][0], d[2 * plane + 2 * j + 1] = h3[j][1];
+            }
         }
     }
     __syncthreads();
@@ -205,16 +251,22 @@ __global__ __launch_bounds__(rows_max_waves(KQB) * 64) void k_proj_rows(ProjArgs
 
         auto mfma_block = [&](int g, int b) {
 #pragma unroll
-            for (int q = 0; q < KQB; ++q) {
-                const float av[4] = {af[q].x, af[q].y, af[q].z, af[q].w};
+            for (int m = 0; m < KQB / 2; ++m) {
+                bf16x8_t a1, a2, a3;
+                split8(af[2 * m], af[2 * m + 1], a1, a2, a3);
 #pragma unroll
                 for (int ct = 0; ct < NCG; ++ct) {
-                    const float4 bq = *reinterpret_cast<const float4 *>(wl + ((g * NCG + ct) * 32 + lr) * p.ldw +
-                                                                         b * KB + hf * KBH + 4 * q);
-                    const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[ct], 0, 0, 0);
+                    const __bf16 *wp = wb + ((g * NCG + ct) * 32 + lr) * p.ldw + b * KB + hf * KBH + 8 * m;
+                    const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t *>(wp);
+                    const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t *>(wp + plane);
+                    const bf16x8_t b3 = *reinterpret_cast<const bf16x8_t *>(wp + 2 * plane);
+                    // smallest terms first
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[ct], 0, 0, 0);
                 }
             }
         };
@@ -278,14 +330,14 @@ struct Choice {
 };
 
 // float4 per lane half and K block the kernel is instantiated for
-const int kKqb[] = {1, 2, 3, 4, 6, 8, 9, 12};
+const int kKqb[] = {2, 4, 6, 8, 10, 12};  // even: one MFMA step takes 8 k from each lane half
 
 // `mw`: number of output columns this launch covers, starting at a.col0 (the whole M, or one
 // 64-column window of a wide epilogue launch)
 bool choose(const ProjArgs &a, int mw, Choice &c) {
     if (a.n <= 0) return false;
     const bool vec = (a.F & 3) == 0 && aligned16(a.x, a.ld_x) && (!a.x_mask || (uintptr_t)a.x_mask % 4 == 0);
-    if (!vec && a.F > 24) return false;  // element-wise operand loads exist for short rows only
+    if (!vec && a.F > 32) return false;  // element-wise operand loads exist for short rows only
     const bool ep = has_epilogue(a);
     if (ep) {
         // the vectorised epilogue: one column group of whole tiles, float4-aligned operands
@@ -320,8 +372,8 @@ bool choose(const ProjArgs &a, int mw, Choice &c) {
     c.ncg = ncg;
     c.plan.nkb = nkb;
     c.plan.ngroups = ngroups;
-    c.plan.ldw = nkb * kqb * 8 + 4;
-    const size_t w_bytes = (size_t)ngroups * ncg * 32 * c.plan.ldw * sizeof(float);
+    c.plan.ldw = nkb * kqb * 8 + 8;  // + 16 bytes: rows start in different banks
+    const size_t w_bytes = (size_t)3 * ngroups * ncg * 32 * c.plan.ldw * 2;  // three bf16 planes
     const size_t strip = (size_t)SR * (ncg * 32 + 4) * sizeof(float);
     // block size that puts the most waves on a CU (160 KB of LDS, 16 waves at <= 128 VGPRs)
     const int max_waves = rows_max_waves(kqb);
@@ -394,13 +446,11 @@ int proj_rows_try(const ProjArgs &a0, int64_t *n_part, int *n_win, bool dry_run,
         if (a0.part_prelu) a.part_prelu = a0.part_prelu + (int64_t)wdx * c.grid * c.plan.wpb;
         int st;
         switch (c.kqb) {
-            case 1: st = launch_kq<1>(a, c, ep, stream); break;
             case 2: st = launch_kq<2>(a, c, ep, stream); break;
-            case 3: st = launch_kq<3>(a, c, ep, stream); break;
             case 4: st = launch_kq<4>(a, c, ep, stream); break;
             case 6: st = launch_kq<6>(a, c, ep, stream); break;
             case 8: st = launch_kq<8>(a, c, ep, stream); break;
-            case 9: st = launch_kq<9>(a, c, ep, stream); break;
+            case 10: st = launch_kq<10>(a, c, ep, stream); break;
             case 12: st = launch_kq<12>(a, c, ep, stream); break;
             default: return MAGIC_ERR_UNSUPPORTED;
         }
