@@ -97,8 +97,11 @@ typedef struct magic_plan {
  * 128-byte aligned rows:  cols [0,C) -> hs [N,C];  cols [C, C+n_score) -> score [N,n_score]
  * (eh then et, model/gat.py:291-292, pre-folded into W by the caller);  cols
  * [C+n_score, M) -> res [N, M-C-n_score] (residual projection, model/gat.py:323).
- * Replaces torch.nn.Linear at model/gat.py:284 and :323.  fp32 in, fp32 accumulate
- * (v_mfma_f32_32x32x2_f32, bit-equal to an fmaf chain over k).
+ * Replaces torch.nn.Linear at model/gat.py:284 and :323.  fp32 in, fp32 accumulate, fp32-grade
+ * products: the main kernel splits each operand into three bf16 pieces and keeps the six
+ * leading cross products (v_mfma_f32_32x32x16_bf16; what it drops is below one fp32 rounding
+ * of the product), the fallback kernels use v_mfma_f32_32x32x2_f32.  Fixed summation order:
+ * results are reproducible run to run.
  * ---------------------------------------------------------------------------------- */
 int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_score, int32_t res_c,
                    const float *x, int64_t ld_x,

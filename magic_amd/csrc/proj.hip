@@ -1,5 +1,7 @@
 // Dense node projection  Y = (X (.) mask) . op(W)  in exact fp32 on the matrix cores
 // (v_mfma_f32_32x32x2_f32: bit-equal to an fmaf chain over k), with a fused epilogue.
+// These LDS-staged kernels are the fallback: shapes and alignments the row-owner kernel of
+// proj_rows.hip (split-bf16 MFMA) accepts run there.
 //
 // Forward use: output columns are routed to three destinations -- the gathered operand hs
 // (own buffer, 16-byte aligned rows), the 2H attention score columns, the residual projection.
