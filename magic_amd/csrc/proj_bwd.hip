@@ -1,12 +1,14 @@
-// Weight gradient of the node projection:  dW[M,F] = dY[N,M]^T . X[N,F]  in exact fp32 on the
-// matrix cores.  The reduction runs over the N nodes (hundreds of thousands), the output is
-// tiny, so the kernel streams both inputs once: every MFMA operand is one coalesced
-// 128-byte row segment read straight from HBM (lane l supplies dY[row][m0 + (l&31)] and
-// X[row][f0 + (l&31)], lane half l>>5 selects which of the two rows of the k-step), no LDS
+// Weight gradient of the node projection:  dW[M,F] = dY[N,M]^T . X[N,F]  on the matrix cores with
+// split-bf16 products (bf16_split.h: fp32-grade results, fp32 accumulation).  The reduction runs
+// over the N nodes (hundreds of thousands), the output is tiny, so the kernel streams both inputs
+// once: every operand element is part of one coalesced 128-byte row segment read straight from
+// HBM (lane l supplies dY[row][m0 + (l&31)] and X[row][f0 + (l&31)] for the eight rows
+// r + 8*(l>>5) .. + 7 of a 16-row step, which are the lane's eight k of one 32x32x16 MFMA), no LDS
 // staging.  Each wave owns a strip of rows and a register tile of the output; the waves of a
 // block are summed through LDS in wave order and the block partials by a second launch in
 // block order (bitwise reproducible, no atomics).
 #include "common.h"
+#include "bf16_split.h"
 
 namespace {
 
@@ -63,43 +65,51 @@ __global__ __launch_bounds__(256) void k_proj_dw(DwArgs a) {
 #ifndef MAGIC_DW_U
 #define MAGIC_DW_U 8
 #endif
-    constexpr int U = MAGIC_DW_U;  // k-steps in flight
+    constexpr int U = MAGIC_DW_U;  // rows per lane and step: the eight k of one 32x32x16 MFMA
+    static_assert(U == 8, "one MFMA step takes eight rows from each lane half");
     const int64_t last = a.n - 1;
     for (int64_t r = r_beg; r < r_end; r += 2 * U) {
-        float av[U][MT], bv[U][FT];
-        uint8_t mv[U][FT];
+        float av[MT][U], bv[FT][U];
+        uint8_t mv[FT][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t row = r + 2 * u + hf;
+            const int64_t row = r + U * hf + u;
             const int64_t rc = row < last ? row : last;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[u][mt] = a.dy[rc * a.ld_dy + mcol[mt]];
+            for (int mt = 0; mt < MT; ++mt) av[mt][u] = a.dy[rc * a.ld_dy + mcol[mt]];
 #pragma unroll
-            for (int ft = 0; ft < FT; ++ft) bv[u][ft] = a.x[rc * a.ld_x + fcol[ft]];
+            for (int ft = 0; ft < FT; ++ft) bv[ft][u] = a.x[rc * a.ld_x + fcol[ft]];
             if (a.x_mask) {
 #pragma unroll
-                for (int ft = 0; ft < FT; ++ft) mv[u][ft] = a.x_mask[rc * a.F + fcol[ft]];
+                for (int ft = 0; ft < FT; ++ft) mv[ft][u] = a.x_mask[rc * a.F + fcol[ft]];
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool rok = r + 2 * u + hf < r_end;
+            const bool rok = r + U * hf + u < r_end;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[u][mt] = (rok && mok[mt]) ? av[u][mt] : 0.f;
+            for (int mt = 0; mt < MT; ++mt) av[mt][u] = (rok && mok[mt]) ? av[mt][u] : 0.f;
 #pragma unroll
             for (int ft = 0; ft < FT; ++ft) {
-                float b = (rok && fok[ft]) ? bv[u][ft] : 0.f;
-                if (a.x_mask) b = mv[u][ft] ? b * a.x_scale : 0.f;
-                bv[u][ft] = b;
+                float b = (rok && fok[ft]) ? bv[ft][u] : 0.f;
+                if (a.x_mask) b = mv[ft][u] ? b * a.x_scale : 0.f;
+                bv[ft][u] = b;
             }
         }
+        magic::bf16x8_t a1[MT], a2[MT], a3[MT], b1[FT], b2[FT], b3[FT];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int mt = 0; mt < MT; ++mt)
+            magic::split8(make_float4(av[mt][0], av[mt][1], av[mt][2], av[mt][3]),
+                          make_float4(av[mt][4], av[mt][5], av[mt][6], av[mt][7]), a1[mt], a2[mt], a3[mt]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+        for (int ft = 0; ft < FT; ++ft)
+            magic::split8(make_float4(bv[ft][0], bv[ft][1], bv[ft][2], bv[ft][3]),
+                          make_float4(bv[ft][4], bv[ft][5], bv[ft][6], bv[ft][7]), b1[ft], b2[ft], b3[ft]);
 #pragma unroll
-                for (int ft = 0; ft < FT; ++ft)
-                    acc[mt][ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt], bv[u][ft], acc[mt][ft], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft)
+                magic::mfma_split6(acc[mt][ft], a1[mt], a2[mt], a3[mt], b1[ft], b2[ft], b3[ft]);
     }
     // waves 1..3 park their tiles in LDS; wave 0 adds them in wave order and writes the block partial
     constexpr int TILE = MT * FT * 16 * 64;

@@ -1,13 +1,7 @@
 // Row-owner variant of the dense node projection, laid out for memory-level parallelism.
 //
-// Arithmetic: fp32 operands are split into three bf16 pieces each (a = a1 + a2 + a3 exactly: 8 + 8
-// + 8 significant bits, round-to-nearest at every step) and the six leading cross products
-// a1b1, a1b2, a2b1, a2b2, a1b3, a3b1 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Every
-// kept product is exact; the dropped ones (a2b3, a3b2, a3b3) are below 2^-23 |a||b|, the size of
-// one fp32 rounding.  Six bf16 MFMAs cover 16 k in 6 x 32 cycles where the fp32 MFMA needs
-// 8 x 64: the matrix pipe is busy 2.7x less for fp32-grade results (measured against the fp32
-// MFMA kernels of proj.hip in the tests).  Sum order is fixed, results are reproducible.
-//
+// Arithmetic: split-bf16 products (bf16_split.h): fp32-grade results with the matrix pipe busy 2.7x
+// less than with the fp32 MFMA of the LDS-staged kernels in proj.hip.  Fixed summation order.
 //
 //  * A operand straight from HBM: lane l owns row (l & 31) of the wave's 32-row tile and the
 //    half (l >> 5) of every K block -- KQB consecutive float4 of its own row, which are exactly the
@@ -21,8 +15,15 @@
 //  * <= 128 VGPRs (168 for long row segments): 16 (12) waves per CU keep enough loads in flight
 //    without software prefetch.
 #include "proj_common.h"
+#include "bf16_split.h"
 
 namespace {
+
+using magic::bf16x8_t;
+using magic::bf16x2_t;
+using magic::f32x2_t;
+using magic::split2;
+using magic::split8;
 
 struct RowsPlan {
     int nkb;      // K blocks of KQB*8
@@ -71,32 +72,6 @@ __device__ __forceinline__ void route_store_elems(const ProjArgs &a, float4 v, i
             a.score[row * a.NS + (c - s0)] = e[j];
         else if (c < a.M)
             a.res[row * a.ld_res + (c - r0)] = e[j];
-    }
-}
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-// v = h1 + h2 + h3 exactly (round-to-nearest pieces, v_cvt_pk_bf16_f32), two values at a time
-__device__ __forceinline__ void split2(f32x2_t v, bf16x2_t &h1, bf16x2_t &h2, bf16x2_t &h3) {
-    h1 = __builtin_convertvector(v, bf16x2_t);
-    const f32x2_t r1 = v - __builtin_convertvector(h1, f32x2_t);
-    h2 = __builtin_convertvector(r1, bf16x2_t);
-    const f32x2_t r2 = r1 - __builtin_convertvector(h2, f32x2_t);
-    h3 = __builtin_convertvector(r2, bf16x2_t);
-}
-
-// eight consecutive k of a lane's row -> the three bf16 operand vectors of one MFMA step
-__device__ __forceinline__ void split8(float4 lo, float4 hi, bf16x8_t &p1, bf16x8_t &p2, bf16x8_t &p3) {
-    const f32x2_t v[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        bf16x2_t h1, h2, h3;
-        split2(v[j], h1, h2, h3);
-        p1[2 * j] = h1[0], p1[2 * j + 1] = h1[1];
-        p2[2 * j] = h2[0], p2[2 * j + 1] = h2[1];
-        p3[2 * j] = h3[0], p3[2 * j + 1] = h3[1];
     }
 }
 
@@ -260,13 +235,7 @@ __global__ __launch_bounds__(rows_max_waves(KQB) * 64) void k_proj_rows(ProjArgs
                     const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t *>(wp);
                     const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t *>(wp + plane);
                     const bf16x8_t b3 = *reinterpret_cast<const bf16x8_t *>(wp + 2 * plane);
-                    // smallest terms first
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[ct], 0, 0, 0);
+                    magic::mfma_split6(acc[ct], a1, a2, a3, b1, b2, b3);
                 }
             }
         };
