@@ -201,21 +201,11 @@ def _rows(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return t if t.stride(-1) == 1 else t.contiguous()
 
 
-def _gemm_regime(k: int, m: int) -> bool:
-    """Plain projections this large (hidden 256 with its 1024-wide concatenation) are MFMA-bound
-    GEMMs, not streams: the library BLAS runs them at ~130 TFLOP/s, the streaming kernels of this
-    library at ~65.  Everything with a fused mask / epilogue / routed output stays here."""
-    return k * m >= (1 << 17) and min(k, m) >= 128
-
-
 def proj_fwd(x: torch.Tensor, w: torch.Tensor, out_c: int, n_score: int, res_c: int,
              x_mask: Optional[torch.Tensor] = None, x_scale: float = 1.0):
     """hs [N,out_c], score [N,n_score] | None, res [N,res_c] | None  =  split((x * mask * scale) @ w.T)."""
     lib = load()
     assert x.dim() == 2 and w.dim() == 2 and w.shape[1] == x.shape[1] and w.shape[0] == out_c + n_score + res_c
-    if x_mask is None and n_score == 0 and res_c == 0 and _gemm_regime(x.shape[1], out_c):
-        _dev(x, torch.float32, "x"), _dev(w, torch.float32, "w")       # GPU fp32 only, as everywhere else
-        return torch.mm(x, w.t()), None, None
     x = _rows(x)
     w = w.contiguous()
     N, F = x.shape
@@ -240,10 +230,6 @@ def proj_bwd_input(dy: torch.Tensor, w: torch.Tensor, add: Optional[torch.Tensor
     See ``magic_proj_epilogue`` in include/magic_hip.h for the epilogue order."""
     lib = load()
     assert dy.dim() == 2 and w.dim() == 2 and dy.shape[1] == w.shape[0]
-    plain = add is None and out_mask is None and add2 is None and act_out is None and not want_col_sum
-    if plain and out is None and _gemm_regime(w.shape[0], w.shape[1]):
-        _dev(dy, torch.float32, "dy"), _dev(w, torch.float32, "w")
-        return torch.mm(dy, w), None, None
     dy = _rows(dy)
     w = w.contiguous()
     add, add2, act_out = _rows(add), _rows(add2), _rows(act_out)

@@ -456,39 +456,38 @@ __global__ __launch_bounds__(256) void k_bwd_deh_heavy2(BwdArgs a, int C) {
 }
 
 // ---- d_ee_table[t,h] = sum over edges of type t of d_logit[e,h] ---------------------------
-// Every thread keeps TMAX x H running sums in registers (compare-select per type, no
-// indexing), blocks reduce through LDS in thread order, a last launch adds the block rows.
-template <int H, int TMAX>
-__global__ __launch_bounds__(256) void k_bwd_table_partial(BwdArgs a) {
-    __shared__ float red[256];
-    float acc[TMAX][H];
+// Every thread owns a private column of an LDS table [e_dim*H][128] (bank = thread: no conflicts,
+// no atomics) and adds its edges there in edge order; the 128 columns of a row are then summed
+// in a fixed tree and a last launch adds the block rows.
+constexpr int TBL_THREADS = 128;
+
+template <int H>
+__global__ __launch_bounds__(TBL_THREADS) void k_bwd_table_partial(BwdArgs a) {
+    extern __shared__ float tbl[];  // [e_dim*H][TBL_THREADS]
+    const int tid = threadIdx.x;
+    const int rows = a.e_dim * H;
+    for (int r = 0; r < rows; ++r) tbl[r * TBL_THREADS + tid] = 0.f;
+    const int stride = gridDim.x * TBL_THREADS;
+    int i = blockIdx.x * TBL_THREADS + tid;
+    for (; i + stride < a.E; i += 2 * stride) {  // two edges per round: their loads are in flight together
+        const int t0 = a.etype[i], t1 = a.etype[i + stride];
+        const HeadVec<H> d0 = ldh<H>(a.dl + (int64_t)i * H), d1 = ldh<H>(a.dl + (int64_t)(i + stride) * H);
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t)
+        for (int h = 0; h < H; ++h) tbl[(t0 * H + h) * TBL_THREADS + tid] += d0.v[h];
 #pragma unroll
-        for (int h = 0; h < H; ++h) acc[t][h] = 0.f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.E; i += gridDim.x * 256) {
-        const int ty = a.etype[i];
-        float dl[H];
-#pragma unroll
-        for (int h = 0; h < H; ++h) dl[h] = a.dl[(int64_t)i * H + h];
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t)
-#pragma unroll
-            for (int h = 0; h < H; ++h) acc[t][h] += (ty == t) ? dl[h] : 0.f;
+        for (int h = 0; h < H; ++h) tbl[(t1 * H + h) * TBL_THREADS + tid] += d1.v[h];
     }
+    if (i < a.E) {
+        const int t0 = a.etype[i];
+        const HeadVec<H> d0 = ldh<H>(a.dl + (int64_t)i * H);
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            if (t < a.e_dim) {  // uniform
-                float v = wave_sum(acc[t][h]);
-                __syncthreads();
-                if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-                __syncthreads();
-                if (threadIdx.x == 0)
-                    a.ws_table[(int64_t)blockIdx.x * a.e_dim * H + t * H + h] = (red[0] + red[1]) + (red[2] + red[3]);
-            }
-        }
+        for (int h = 0; h < H; ++h) tbl[(t0 * H + h) * TBL_THREADS + tid] += d0.v[h];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < rows; r += TBL_THREADS / 64) {
+        const float v = wave_sum(tbl[r * TBL_THREADS + lane] + tbl[r * TBL_THREADS + 64 + lane]);
+        if (lane == 0) a.ws_table[(int64_t)blockIdx.x * rows + r] = v;
     }
 }
 
@@ -515,16 +514,15 @@ int launch_table(BwdArgs &a, hipStream_t stream) {
         if (hipMemsetAsync(a.d_table, 0, sizeof(float) * a.e_dim * H, stream) != hipSuccess) return MAGIC_ERR_RUNTIME;
         return MAGIC_OK;
     }
-    if (a.e_dim <= 8)
-        MAGIC_LAUNCH("gat_bwd_table_partial", (k_bwd_table_partial<H, 8>), a.grid_table, 256, 0, stream, a);
-    else if (a.e_dim <= 16)
-        MAGIC_LAUNCH("gat_bwd_table_partial", (k_bwd_table_partial<H, 16>), a.grid_table, 256, 0, stream, a);
-    else if (a.e_dim <= 24)
-        MAGIC_LAUNCH("gat_bwd_table_partial", (k_bwd_table_partial<H, 24>), a.grid_table, 256, 0, stream, a);
-    else if (a.e_dim <= 32)
-        MAGIC_LAUNCH("gat_bwd_table_partial", (k_bwd_table_partial<H, 32>), a.grid_table, 256, 0, stream, a);
-    else
-        return MAGIC_ERR_UNSUPPORTED;
+    const size_t sh = (size_t)a.e_dim * H * TBL_THREADS * sizeof(float);
+    static size_t attr_bytes = 0;
+    if (sh > 48 * 1024 && sh > attr_bytes) {
+        if (hipFuncSetAttribute((const void *)k_bwd_table_partial<H>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sh) != hipSuccess)
+            return MAGIC_ERR_RUNTIME;
+        attr_bytes = sh;
+    }
+    MAGIC_LAUNCH("gat_bwd_table_partial", (k_bwd_table_partial<H>), a.grid_table, TBL_THREADS, sh, stream, a);
     MAGIC_LAUNCH("gat_bwd_table_final", k_bwd_table_final, a.e_dim * H, 256, 0, stream, a, H);
     return MAGIC_OK;
 }
@@ -565,7 +563,7 @@ static int light_grid(int N, int H, int D) {
     int npb = 256 / (H * D / 4);
     return stride_grid(N, npb, 2048);
 }
-static int table_grid(int E) { return stride_grid(E, 256 * 8, 1024); }
+static int table_grid(int E) { return stride_grid(E, 128 * 8, 1024); }
 
 }  // namespace magic
 

@@ -20,6 +20,7 @@
 
 namespace magic {
 int proj_rows_try(const ProjArgs &a, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream);
+int proj_gemm_try(const ProjArgs &a, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream);
 }
 
 namespace {
@@ -460,6 +461,8 @@ int64_t n_partials(const ProjArgs &a, int nct) {
 int dispatch(const ProjArgs &a0, hipStream_t stream) {
     ProjArgs a = a0;
     a.col0 = 0;
+    const int st_gemm = magic::proj_gemm_try(a, nullptr, nullptr, false, stream);
+    if (st_gemm != MAGIC_ERR_UNSUPPORTED) return st_gemm;
     const int st_rows = magic::proj_rows_try(a, nullptr, nullptr, false, stream);
     if (st_rows != MAGIC_ERR_UNSUPPORTED) return st_rows;
     const int tiles = (a.M + 31) / 32;
@@ -583,7 +586,8 @@ int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim, const f
     if (sums) {
         const int tiles = (out_dim + 31) / 32;
         a.part_col = static_cast<float *>(workspace);  // provisional: the kernel choice looks at it
-        if (magic::proj_rows_try(a, &np, &n_win, true, stream) != MAGIC_OK) {
+        if (magic::proj_gemm_try(a, &np, &n_win, true, stream) != MAGIC_OK &&
+            magic::proj_rows_try(a, &np, &n_win, true, stream) != MAGIC_OK) {
             if (tiles > 10) return MAGIC_ERR_UNSUPPORTED;  // column sums need a single launch there
             np = n_partials(a, tiles);
             n_win = 1;

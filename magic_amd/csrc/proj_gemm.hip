@@ -1,0 +1,321 @@
+// Block-tiled variant of the dense node projection for the wide layers (hidden 256 and its
+// 1024-wide concatenation), where the projection is a GEMM bound by the matrix pipe rather than
+// a stream: Y[N,M] = (X (.) mask)[N,K] . op(W), K >= 96, M >= 128.
+//
+//  * 128 x 128 output tile per block of four waves (2 x 2, 64 x 64 per wave = 2 x 2 MFMA tiles),
+//    K in steps of 32.
+//  * split-bf16 products (bf16_split.h): both operand tiles are split into their three bf16
+//    planes once, when they are staged in LDS, and every wave reads its MFMA operands from
+//    there as 16-byte fragments -- the split costs (M/128 + N/128) / 2 VALU passes per element
+//    instead of one per MFMA tile, and 6 bf16 MFMAs replace 8 fp32 MFMAs of twice their length.
+//  * one LDS buffer, register prefetch: the X loads of step k+2 and the W loads of step k+1 are
+//    issued before the MFMAs of step k and land in registers while those run; two resident blocks
+//    per CU overlap one block's staging with the other's MFMAs.
+//  * rows of 40 bf16 (80 bytes): the 16-byte operand reads of 16 consecutive lanes cover all 64
+//    banks exactly once.
+//  * blockIdx is remapped so that the column blocks of one row block run on the same XCD, next to
+//    each other in time: the X tile comes out of that XCD's L2 for all but the first of them.
+//  * the accumulators leave through a 16-row LDS strip per wave as whole rows of float4 (the
+//    epilogue of proj_rows.hip: routed outputs, or the fused input-gradient chain with its sums).
+#include "proj_common.h"
+#include "bf16_split.h"
+
+namespace {
+
+using magic::bf16x2_t;
+using magic::bf16x8_t;
+using magic::f32x2_t;
+using magic::split2;
+
+constexpr int GBM = 128, GBN = 128, GBK = 32;
+constexpr int GLD = GBK + 8;       // bf16 per staged row
+constexpr int PLANE = 128 * GLD;   // bf16 per plane of one operand tile
+constexpr size_t GEMM_LDS = (size_t)2 * 3 * PLANE * 2;
+constexpr int LDO = 64 + 4;        // strip row stride (floats)
+
+struct GemmPlan {
+    int col_blocks;
+    int64_t row_blocks;
+    int64_t per_xcd;  // blocks per XCD (grid = 8 * per_xcd)
+    int n_win;        // 64-column windows that hold output columns
+};
+
+union Pack4 {
+    bf16x2_t h[2];
+    uint2 u;
+};
+
+// four consecutive k of one tile row -> the three planes (8 bytes each)
+__device__ __forceinline__ void stage4(__bf16 *dst, float4 v) {
+    Pack4 p1, p2, p3;
+    split2(f32x2_t{v.x, v.y}, p1.h[0], p2.h[0], p3.h[0]);
+    split2(f32x2_t{v.z, v.w}, p1.h[1], p2.h[1], p3.h[1]);
+    *reinterpret_cast<uint2 *>(dst) = p1.u;
+    *reinterpret_cast<uint2 *>(dst + PLANE) = p2.u;
+    *reinterpret_cast<uint2 *>(dst + 2 * PLANE) = p3.u;
+}
+
+// four consecutive tile rows (output columns) at one k -> the three planes, element by element
+__device__ __forceinline__ void stage4_t(__bf16 *dst, float4 v) {
+    bf16x2_t a1, a2, a3, b1, b2, b3;
+    split2(f32x2_t{v.x, v.y}, a1, a2, a3);
+    split2(f32x2_t{v.z, v.w}, b1, b2, b3);
+    dst[0] = a1[0], dst[GLD] = a1[1], dst[2 * GLD] = b1[0], dst[3 * GLD] = b1[1];
+    dst += PLANE;
+    dst[0] = a2[0], dst[GLD] = a2[1], dst[2 * GLD] = b2[0], dst[3 * GLD] = b2[1];
+    dst += PLANE;
+    dst[0] = a3[0], dst[GLD] = a3[1], dst[2 * GLD] = b3[0], dst[3 * GLD] = b3[1];
+}
+
+template <bool EP>
+__global__ __launch_bounds__(256, 2) void k_proj_gemm(ProjArgs a, GemmPlan p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __bf16 *sA = reinterpret_cast<__bf16 *>(smem);
+    __bf16 *sB = sA + 3 * PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, hf = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    // consecutive block ids alternate over the 8 XCDs: give every XCD one contiguous range of tiles
+    const int64_t pid = (int64_t)(blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+    if (pid >= p.row_blocks * p.col_blocks) return;
+    const int cb = (int)(pid % p.col_blocks);
+    const int64_t rb = pid / p.col_blocks;
+    const int64_t row0 = rb * GBM;
+    const int colb = cb * GBN;
+    const bool nt = a.w_cs == 1;  // weight rows are output columns (forward); else stored [k][column]
+
+    float16_t acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+    // column tiles of this wave that hold output columns at all (uniform per wave)
+    bool tile_ok[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) tile_ok[ct] = colb + wc * 64 + ct * 32 < a.M;
+
+    // staging roles: 8 threads per tile row (4 k each), 32 tile rows per pass, 4 passes
+    const int sr = tid >> 3, sk = (tid & 7) * 4;
+    const int64_t last = a.n - 1;
+    auto load_a = [&](int kb, float4 (&ra)[4], uint32_t (&rm)[4]) {
+        const int k = kb * GBK + sk;
+        const int kc = k < a.F ? k : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t row = row0 + sr + 32 * j;
+            const int64_t rc = row < last ? row : last;
+            ra[j] = *reinterpret_cast<const float4 *>(a.x + rc * a.ld_x + kc);
+            if (a.x_mask) rm[j] = *reinterpret_cast<const uint32_t *>(a.x_mask + rc * a.F + kc);
+        }
+    };
+    auto load_w = [&](int kb, float4 (&rw)[4]) {
+        if (nt) {
+            const int k = kb * GBK + sk;
+            const int kc = k < a.F ? k : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = colb + sr + 32 * j;
+                const int cc = c < a.M ? c : a.M - 1;
+                rw[j] = *reinterpret_cast<const float4 *>(a.w + (int64_t)cc * a.w_rs + kc);
+            }
+        } else {  // one k per thread row, four consecutive columns per thread
+            const int kk = kb * GBK + sr;
+            const int kkc = kk < a.F ? kk : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = colb + sk + 32 * j;
+                const int cc = c < a.M ? c : 0;
+                rw[j] = *reinterpret_cast<const float4 *>(a.w + (int64_t)kkc * a.w_cs + cc);
+            }
+        }
+    };
+    auto store_tiles = [&](int kb, const float4 (&ra)[4], const uint32_t (&rm)[4], const float4 (&rw)[4]) {
+        const int k = kb * GBK + sk;
+        const bool kok = k < a.F;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 v = ra[j];
+            if (a.x_mask) {
+                v.x = (rm[j] & 0xffu) ? v.x * a.x_scale : 0.f;
+                v.y = (rm[j] & 0xff00u) ? v.y * a.x_scale : 0.f;
+                v.z = (rm[j] & 0xff0000u) ? v.z * a.x_scale : 0.f;
+                v.w = (rm[j] & 0xff000000u) ? v.w * a.x_scale : 0.f;
+            }
+            if (!kok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            stage4(sA + (sr + 32 * j) * GLD + sk, v);
+        }
+        if (nt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 v = rw[j];
+                if (!kok || colb + sr + 32 * j >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                stage4(sB + (sr + 32 * j) * GLD + sk, v);
+            }
+        } else {
+            const bool kkok = kb * GBK + sr < a.F;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 v = rw[j];
+                if (!kkok || colb + sk + 32 * j >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                stage4_t(sB + (sk + 32 * j) * GLD + sr, v);
+            }
+        }
+    };
+    auto mfma_step = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t ap[2][3], bp[2][3];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    ap[rt][pl] = *reinterpret_cast<const bf16x8_t *>(sA + pl * PLANE + (wr * 64 + rt * 32 + lr) * GLD +
+                                                                     s * 16 + hf * 8);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                if (tile_ok[ct]) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bp[ct][pl] = *reinterpret_cast<const bf16x8_t *>(sB + pl * PLANE +
+                                                                         (wc * 64 + ct * 32 + lr) * GLD + s * 16 + hf * 8);
+                }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                if (tile_ok[ct]) {
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        magic::mfma_split6(acc[rt][ct], ap[rt][0], ap[rt][1], ap[rt][2], bp[ct][0], bp[ct][1], bp[ct][2]);
+                }
+        }
+    };
+
+    // X tiles are prefetched two K steps ahead (HBM latency), W tiles one (they come out of L2)
+    const int nk = (a.F + GBK - 1) / GBK;
+    float4 ra0[4], ra1[4], rw[4];
+    uint32_t rm0[4], rm1[4];
+    load_a(0, ra0, rm0);
+    load_w(0, rw);
+    if (nk > 1) load_a(1, ra1, rm1);
+    for (int kb = 0; kb < nk; kb += 2) {
+        __syncthreads();  // the previous step's operand reads are done
+        store_tiles(kb, ra0, rm0, rw);
+        __syncthreads();
+        if (kb + 1 < nk) load_w(kb + 1, rw);
+        if (kb + 2 < nk) load_a(kb + 2, ra0, rm0);
+        mfma_step();
+        if (kb + 1 >= nk) break;
+        __syncthreads();
+        store_tiles(kb + 1, ra1, rm1, rw);
+        __syncthreads();
+        if (kb + 2 < nk) load_w(kb + 2, rw);
+        if (kb + 3 < nk) load_a(kb + 3, ra1, rm1);
+        mfma_step();
+    }
+    __syncthreads();  // LDS becomes the transposition strips
+
+    float *os = reinterpret_cast<float *>(smem) + wave * (SR * LDO);
+    const int gc = colb + wc * 64 + (lane & 15) * 4;  // this lane's four columns in every strip row
+    const float w = (EP && a.prelu_w) ? a.prelu_w[0] : 1.f;
+    const float inv_w = w > 0.f ? 1.f / w : 0.f;
+    float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dprelu = 0.f;
+    Dst d;
+    d.p = nullptr, d.ld = 0, d.mode = 0;
+    if (!EP) d = route(a, gc);
+    if (tile_ok[0]) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8)
+                        os[((r8 & 3) + 8 * (r8 >> 2) + 4 * hf) * LDO + ct * 32 + lr] = acc[rt][ct][h * 8 + r8];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+                for (int i = 0; i < 4; ++i) {
+                    const int r = (lane >> 4) + 4 * i;
+                    const float4 q = *reinterpret_cast<const float4 *>(os + r * LDO + (lane & 15) * 4);
+                    const int64_t orow = row0 + wr * 64 + rt * 32 + h * SR + r;
+                    if (EP) {
+                        if (gc < a.C) epi_store4<true>(a, q, orow, gc, w, inv_w, cs4, dprelu);
+                    } else if (orow < a.n) {
+                        if (d.mode == 1) *reinterpret_cast<float4 *>(d.p + orow * d.ld) = q;
+                        if (d.mode == 2) route_store_elems(a, q, orow, gc);
+                    }
+                }
+            }
+    }
+    if (EP && a.part_col) {
+        // lanes l, l + 16, l + 32, l + 48 hold the same four columns
+        cs4.x += __shfl_xor(cs4.x, 16, 64), cs4.y += __shfl_xor(cs4.y, 16, 64);
+        cs4.z += __shfl_xor(cs4.z, 16, 64), cs4.w += __shfl_xor(cs4.w, 16, 64);
+        cs4.x += __shfl_xor(cs4.x, 32, 64), cs4.y += __shfl_xor(cs4.y, 32, 64);
+        cs4.z += __shfl_xor(cs4.z, 32, 64), cs4.w += __shfl_xor(cs4.w, 32, 64);
+        const int64_t prow = rb * 2 + wr;           // part_col [2*row_blocks, C]
+        if (lane < 16 && gc < a.C) *reinterpret_cast<float4 *>(a.part_col + prow * a.C + gc) = cs4;
+        const int win = cb * 2 + wc;                // part_prelu [n_win, 2*row_blocks]
+        if (a.part_prelu && win < p.n_win) {
+            float s = dprelu;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (lane == 0) a.part_prelu[(int64_t)win * (p.row_blocks * 2) + prow] = s;
+        }
+    }
+}
+
+template <bool EP> int launch(const ProjArgs &a, const GemmPlan &p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_proj_gemm<EP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)GEMM_LDS) != hipSuccess)
+            return MAGIC_ERR_RUNTIME;
+        attr_set = true;
+    }
+    MAGIC_LAUNCH(a.name, (k_proj_gemm<EP>), (unsigned)(p.per_xcd * 8), 256, GEMM_LDS, stream, a, p);
+    return magic::launch_status();
+}
+
+}  // namespace
+
+namespace magic {
+
+// Runs the projection on the block-tiled kernel when it is a GEMM (wide K and M) and the operand
+// alignment allows it; MAGIC_ERR_UNSUPPORTED otherwise.  `n_part` / `n_win` describe the partial
+// sums an epilogue launch writes: part_col [n_part, C], part_prelu [n_win, n_part].
+int proj_gemm_try(const ProjArgs &a, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream) {
+    if (a.n <= 0 || a.F < 96 || a.M < 128 || a.col0 != 0) return MAGIC_ERR_UNSUPPORTED;
+    if ((a.F & 3) || !aligned16(a.x, a.ld_x)) return MAGIC_ERR_UNSUPPORTED;
+    if (a.x_mask && ((uintptr_t)a.x_mask & 3)) return MAGIC_ERR_UNSUPPORTED;
+    if (a.w_cs == 1) {
+        if (!aligned16(a.w, a.w_rs)) return MAGIC_ERR_UNSUPPORTED;
+    } else {
+        if (a.w_rs != 1 || (a.M & 3) || !aligned16(a.w, a.w_cs)) return MAGIC_ERR_UNSUPPORTED;
+    }
+    const bool ep = has_epilogue(a);
+    if (ep) {
+        if (a.M != a.C || (a.C & 3) || !aligned16(a.hs, a.ld_hs)) return MAGIC_ERR_UNSUPPORTED;
+        if (a.add && !aligned16(a.add, a.ld_add)) return MAGIC_ERR_UNSUPPORTED;
+        if (a.add2 && !aligned16(a.add2, a.ld_add2)) return MAGIC_ERR_UNSUPPORTED;
+        if (a.act_out && (!aligned16(a.act_out, a.ld_act) || !aligned16(a.act_pre, a.C))) return MAGIC_ERR_UNSUPPORTED;
+        if (a.out_mask && ((uintptr_t)a.out_mask & 3)) return MAGIC_ERR_UNSUPPORTED;
+        if (a.part_col && ((uintptr_t)a.part_col & 15)) return MAGIC_ERR_UNSUPPORTED;
+    }
+    GemmPlan p;
+    p.col_blocks = (a.M + GBN - 1) / GBN;
+    p.row_blocks = (a.n + GBM - 1) / GBM;
+    const int64_t blocks = p.row_blocks * p.col_blocks;
+    p.per_xcd = (blocks + 7) / 8;
+    p.n_win = (a.M + 63) / 64;
+    if (p.per_xcd * 8 > 0x7fffffffLL) return MAGIC_ERR_UNSUPPORTED;
+    if (n_part) *n_part = p.row_blocks * 2;
+    if (n_win) *n_win = p.n_win;
+    if (dry_run) return MAGIC_OK;
+    return ep ? launch<true>(a, p, stream) : launch<false>(a, p, stream);
+}
+
+}  // namespace magic

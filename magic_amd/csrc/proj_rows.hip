@@ -32,49 +32,6 @@ struct RowsPlan {
     int wpb;      // waves per block
 };
 
-constexpr int SR = 16;  // rows per transposition strip
-
-// where the four output columns [gc, gc+4) of a lane go: one float4 destination (hs | score | res
-// all keep float4 alignment, see choose()), or nowhere (columns past M)
-struct Dst {
-    float *p;
-    int64_t ld;
-    int mode;  // 0 none, 1 float4, 2 element-wise (single-tile outputs only)
-};
-
-__device__ __forceinline__ Dst route(const ProjArgs &a, int gc) {
-    Dst d;
-    d.p = nullptr, d.ld = 0, d.mode = 0;
-    const int s0 = a.C, r0 = a.C + a.NS;
-    if (gc + 4 <= s0 && ((uintptr_t)a.hs & 15) == 0 && (a.ld_hs & 3) == 0) {
-        d.p = a.hs + gc, d.ld = a.ld_hs, d.mode = 1;
-    } else if (gc >= s0 && gc + 4 <= r0 && ((gc - s0) & 3) == 0 && (a.NS & 3) == 0 && ((uintptr_t)a.score & 15) == 0) {
-        d.p = a.score + (gc - s0), d.ld = a.NS, d.mode = 1;
-    } else if (gc >= r0 && gc + 4 <= a.M && ((gc - r0) & 3) == 0 && (a.ld_res & 3) == 0 &&
-               ((uintptr_t)a.res & 15) == 0) {
-        d.p = a.res + (gc - r0), d.ld = a.ld_res, d.mode = 1;
-    } else if (gc < a.M) {
-        d.mode = 2;
-    }
-    return d;
-}
-
-// element-wise routing of a float4 that straddles destinations or lacks float4 alignment
-__device__ __forceinline__ void route_store_elems(const ProjArgs &a, float4 v, int64_t row, int c4) {
-    const int s0 = a.C, r0 = a.C + a.NS;
-    const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = c4 + j;
-        if (c < s0)
-            a.hs[row * a.ld_hs + c] = e[j];
-        else if (c < r0)
-            a.score[row * a.NS + (c - s0)] = e[j];
-        else if (c < a.M)
-            a.res[row * a.ld_res + (c - r0)] = e[j];
-    }
-}
-
 // The lane's KQB float4 of one K block of its own row (k in [k0, k0 + 4*KQB)), dropout mask applied.
 // Loads are unconditional (clamped row `rc`, clamped column): rows past the end and columns past F
 // come back as zeros.  `vec`: rows are 16-byte aligned and F % 4 == 0; the element-wise form only
