@@ -2,14 +2,16 @@
 """Benchmark of the MAGIC hot path on MI355X.
 
 One "step" = one training step of the masked-GAT auto-encoder (``compute_loss`` forward,
-backward, Adam update) on one E3-THEIA-shaped synthetic graph per GPU (N=700,000 nodes,
-E=3,000,000 edges, n_dim 5, e_dim 17, hidden 64, 3 layers, dropout on), inputs resident in
-HBM.  With N GPUs every rank steps on its own graph and the flat gradient buffer is
-all-reduced once per step (weak scaling).  ``value`` = edges of all ranks / step time.
+backward, Adam update; dropout on) on one batch, inputs resident in HBM.  The default workload
+is StreamSpot batch-level training: a batch of 12 StreamSpot-sized graphs per GPU (union graph
+N=96,000 nodes, E=2,040,000 edges, n_dim 8, e_dim 20, hidden 256, 4 layers), every rank on its
+own batch, the flat gradient buffer all-reduced once per step (weak scaling).
+``value`` = edges of all ranks / step time.
 
-A second leg times the KNN outlier scorer (k=10, d=64, E3-Trace-sized train set of
-2,604,530 rows sharded over the ranks, a batch of queries per step) and is reported under
-``"knn"`` in the same JSON line.
+Further legs in the same JSON line: ``"entity_level"`` -- the same step on one E3-THEIA-shaped
+full graph (N=700,000, E=3,000,000, hidden 64, 3 layers; single GPU runs only) -- and ``"knn"``
+-- the KNN outlier scorer (k=10, d=64, E3-Trace-sized train set of 2,604,530 rows sharded over
+the ranks, a batch of queries per step).
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
        (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
@@ -30,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec
 F64_MFMA_PEAK_TF = 78.6    # MI355X fp64 matrix spec
+F32_MFMA_PEAK_TF = 157.3   # MI355X fp32 matrix spec
 
 
 def parse():
@@ -37,7 +40,9 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="theia", help="synthetic shape name (magic_amd.synth.SHAPES)")
+    p.add_argument("--workload", default="streamspot_batch",
+                   help="streamspot_batch (12 graphs per step) or a synthetic shape name (magic_amd.synth.SHAPES)")
+    p.add_argument("--no-entity", action="store_true", help="skip the E3-THEIA-shaped full-graph leg")
     p.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debugging only)")
     p.add_argument("--knn-train", type=int, default=2604530)
     p.add_argument("--knn-queries", type=int, default=65536)
@@ -85,27 +90,45 @@ def kernel_bytes(kind, N, E_seg, H, C, res):
     raise ValueError(kind)
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+def dense_work(n, n_dim, hidden, layers, n_pairs):
+    """Algorithmic flops (2 per multiply-add) and HBM bytes (fp32 operands and results once, epilogue
+    operands not counted) of one step's projection launches, per kernel name."""
+    from magic_amd.model.gat import _pad_head_dim
+    H, C, L = 4, hidden, layers
+    dp = _pad_head_dim(n_dim)
+    w = {k: [0.0, 0.0] for k in ("proj_fwd_mfma_f32", "proj_bwd_input_mfma_f32", "proj_bwd_weight_mfma_f32")}
 
+    def add(name, rows, k, m):
+        w[name][0] += 2.0 * rows * k * m
+        w[name][1] += 4.0 * rows * (k + m)
+    for l in range(L):
+        f = n_dim if l == 0 else C
+        m = C + 2 * H + (C if f != C else 0)       # hs | eh, et | linear residual
+        add("proj_fwd_mfma_f32", n, f, m)
+        add("proj_bwd_weight_mfma_f32", n, 2 * f if l == 0 else f, m)  # layer 0 carries the mask-token indicator columns
+        if l > 0:
+            add("proj_bwd_input_mfma_f32", n, m, f)
+    add("proj_fwd_mfma_f32", n, L * C, C)          # encoder_to_decoder
+    add("proj_fwd_mfma_f32", n, C, dp + 2)         # decoder
+    add("proj_bwd_input_mfma_f32", n, C, L * C)
+    add("proj_bwd_input_mfma_f32", n, dp + 2, C)
+    add("proj_bwd_weight_mfma_f32", n, L * C, C)
+    add("proj_bwd_weight_mfma_f32", n, C, dp + 2)
+    add("proj_bwd_weight_mfma_f32", n_pairs, 2 * L * C, C)   # edge-reconstruction MLP
+    add("proj_bwd_weight_mfma_f32", n_pairs, C, 1)
+    return w
+
+
+def gat_leg(args, workload, steps, warmup, world, rank, dev):
+    """Times `steps` training steps of `workload`; returns the numbers of the JSON line."""
     from magic_amd import _lib, synth
-    from magic_amd.model.autoencoder import GMAEModel
+    from magic_amd.model.autoencoder import GMAEModel, global_uniform_negative_sampling
     from magic_amd.parallel import FlatGradAllReduce, broadcast_parameters
     from magic_amd.utils.utils import set_random_seed
 
     batch_graphs = 1
-    shape_name = args.workload
-    if args.workload == "streamspot_batch":   # one batch-level training step: 12 StreamSpot-sized graphs
+    shape_name = workload
+    if workload == "streamspot_batch":   # one batch-level training step: 12 StreamSpot-sized graphs
         shape_name, batch_graphs = "streamspot", 12
     n, e, n_dim, e_dim, hidden, layers = synth.SHAPES[shape_name]
     n, e = max(64, int(n * args.scale)), max(64, int(e * args.scale))
@@ -116,6 +139,7 @@ def main():
     flat = FlatGradAllReduce(model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4, fused=True)
 
+    assembly_ms = None
     if batch_graphs == 1:
         g = synth.make_graph(n, e, n_dim, e_dim, seed=1004 + rank, attrs=False).to(dev)
         g.structure.ensure_csr()
@@ -126,18 +150,26 @@ def main():
         for p_ in parts:
             p_.structure.ensure_csr()
         g = magic_amd.batch(parts)          # model/train.py:39
+        # reported beside the step time: assembling the batch from device-resident graphs with
+        # pre-built CSR (offset-add concatenation, segment plan)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            g2 = magic_amd.batch(parts)
+            g2.structure.ensure_csr()
+        torch.cuda.synchronize()
+        assembly_ms = (time.perf_counter() - t0) / 3 * 1e3
+        del g2
         n = g.num_nodes()
     E = g.num_edges()
     ntype, etype = g.ndata["type"], g.edata["type"]
-    e_attr = torch.nn.functional.one_hot(etype, e_dim).float()
-    g.edata["attr"] = e_attr
+    g.edata["attr"] = torch.nn.functional.one_hot(etype, e_dim).float()
     g.edge_types_csc()
-    total = args.warmup + 2 * args.steps + 2
+    total = warmup + 2 * steps + 2
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
     thr = min(10000, n)
     perms = [torch.randperm(n, device=dev, generator=gen) for _ in range(total)]
     pos = [torch.randint(0, E, (thr,), device=dev, generator=gen) for _ in range(total)]
-    from magic_amd.model.autoencoder import global_uniform_negative_sampling
     negs = [global_uniform_negative_sampling(g, thr, generator=gen) for _ in range(total)]
     counter = [0]
 
@@ -153,21 +185,22 @@ def main():
         opt.step()
         return loss
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
-    dt = timed(step, args.steps, world)
-    ms_per_step = dt / args.steps * 1e3
-    edges_per_s = E * world * args.steps / dt
+    dt = timed(step, steps, world)
+    ms_per_step = dt / steps * 1e3
+    edges_per_s = E * world * steps / dt
 
     # ---- per-kernel timing over a second timed region (HIP events on the launch stream)
     _lib.prof_reset()
     _lib.prof_enable(True)
-    dt_prof = timed(step, args.steps, world)
+    dt_prof = timed(step, steps, world)
     _lib.prof_enable(False)
     prof = _lib.prof_read(64)
     _lib.prof_reset()
 
     roofline = None
+    others = []
     kernels = {}
     if rank == 0:
         s = g.structure
@@ -182,32 +215,76 @@ def main():
         lay = [(4, hidden, "linear" if (n_dim if l == 0 else hidden) != hidden else "identity")
                for l in range(layers)] + [(1, _pad_head_dim(n_dim), None)]
 
-        def avg_bytes(kind, e_seg):
-            return sum(kernel_bytes(kind, n, e_seg, H, C, r) for H, C, r in lay) / len(lay)
-        algo = {"gat_fwd_light": avg_bytes("fwd", e_light_in),
-                "gat_bwd_src_light": avg_bytes("bwd_src", e_light_out),
-                "gat_bwd_dst_light": avg_bytes("bwd_dst", e_light_in)}
+        def step_bytes(kind, e_seg):   # all launches of one step
+            return sum(kernel_bytes(kind, n, e_seg, H, C, r) for H, C, r in lay)
+        algo = {"gat_fwd_light": ("hbm", step_bytes("fwd", e_light_in)),
+                "gat_bwd_src_light": ("hbm", step_bytes("bwd_src", e_light_out)),
+                "gat_bwd_dst_light": ("hbm", step_bytes("bwd_dst", e_light_in))}
+        # a projection is matrix-bound when its flops per byte exceed the ridge of the fp32 matrix peak
+        for name, (fl, by) in dense_work(n, n_dim, hidden, layers, 2 * thr).items():
+            algo[name] = ("mfma", fl) if fl / by > F32_MFMA_PEAK_TF * 1e3 / HBM_PEAK_GBS else ("hbm", by)
         for name, (cnt, tot_ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
             kernels[name] = {"launches": cnt, "avg_us": round(tot_ms / cnt * 1e3, 2),
-                             "total_ms_per_step": round(tot_ms / args.steps, 4)}
+                             "total_ms_per_step": round(tot_ms / steps, 4)}
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        try:
+            traffic_tab = json.load(open(tpath)).get(workload, {}) if os.path.exists(tpath) else {}
+        except Exception:
+            traffic_tab = {}
         ranked = [k for k in sorted(prof, key=lambda k: -prof[k][1]) if k in algo]
-        if ranked:
-            name = ranked[0]
+        for name in ranked[:4]:
             cnt, tot_ms = prof[name]
-            avg_s = tot_ms / cnt * 1e-3
-            achieved = algo[name] / avg_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(args.workload, {}).get(name)
-                except Exception:
-                    traffic = None
-            roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": int(algo[name]), "avg_launch_us": round(avg_s * 1e6, 2),
-                        "launches_per_step": cnt // args.steps,
-                        "profiled_ms_per_step": round(dt_prof / args.steps * 1e3, 3)}
+            per_step = cnt // steps
+            bound, work = algo[name]            # algorithmic bytes / flops of one step's launches of this kernel
+            sec = tot_ms / steps * 1e-3         # their summed duration
+            if bound == "hbm":
+                ach, peak, unit = work / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+            else:
+                ach, peak, unit = work / sec / 1e12, F32_MFMA_PEAK_TF, "TFLOP/s"
+            r = {"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                 "frac": round(ach / peak, 4), "traffic": traffic_tab.get(name),
+                 ("algorithmic_bytes_per_launch" if bound == "hbm" else "algorithmic_flops_per_launch"):
+                     int(work / max(per_step, 1)),
+                 "avg_launch_us": round(tot_ms / cnt * 1e3, 2), "launches_per_step": per_step}
+            if roofline is None:
+                r["profiled_ms_per_step"] = round(dt_prof / steps * 1e3, 3)
+                roofline = r
+            else:
+                others.append(r)
+    desc = {"theia": "E3-THEIA-shaped full graph", "streamspot_batch": "StreamSpot batch-level training, batch of "
+            "12 graphs"}.get(workload, workload)
+    return {"ms_per_step": ms_per_step, "edges_per_s": edges_per_s, "roofline": roofline, "roofline_next": others,
+            "kernels": kernels, "batch_assembly_ms": assembly_ms,
+            "workload": f"{desc} per GPU ({workload}): N={n} E={E} n_dim={n_dim} e_dim={e_dim} hidden={hidden} "
+                        f"layers={layers}; compute_loss fwd + bwd + Adam, dropout on, mask perms and sampled pairs "
+                        "pre-generated",
+            "dims": (n_dim, e_dim, hidden, layers)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    leg = gat_leg(args, args.workload, args.steps, args.warmup, world, rank, dev)
+
+    # ---- entity-level full graph (one GPU per graph in the reference's recipe: single-GPU runs only)
+    entity = None
+    if world == 1 and not args.no_entity and args.workload != "theia":
+        torch.cuda.empty_cache()
+        el = gat_leg(args, "theia", args.steps, args.warmup, world, rank, dev)
+        entity = {"metric": "masked-GAT fwd+bwd edges/sec", "value": round(el["edges_per_s"], 1), "unit": "edges/s",
+                  "ms_per_step": round(el["ms_per_step"], 4), "config": {"workload": el["workload"]},
+                  "roofline": el["roofline"], "roofline_next": el["roofline_next"], "kernels": el["kernels"]}
+        torch.cuda.empty_cache()
 
     # ---- KNN leg
     knn = None
@@ -217,23 +294,23 @@ def main():
     # ---- CPU baselines (rank 0, N=1 only)
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = cpu_gat_baseline(args, n_dim, e_dim, hidden, layers)
+        cpu_baseline = cpu_gat_baseline(args, *leg["dims"])
         if knn is not None:
             knn["cpu_baseline"] = cpu_knn_baseline(args)
 
     if rank == 0:
         out = {
-            "metric": "masked-GAT fwd+bwd edges/sec", "value": round(edges_per_s, 1), "unit": "edges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "metric": "masked-GAT fwd+bwd edges/sec", "value": round(leg["edges_per_s"], 1), "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(leg["ms_per_step"], 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{'E3-THEIA-shaped full graph' if args.workload == 'theia' else args.workload} "
-                                   f"per GPU ({args.workload}): N={n} E={E} "
-                                   f"n_dim={n_dim} e_dim={e_dim} hidden={hidden} layers={layers}; "
-                                   "compute_loss fwd + bwd + Adam, dropout on, mask perms and sampled pairs "
-                                   "pre-generated", "parallelism": f"dp{world} (one graph per rank, "
-                                   "flat-buffer gradient all-reduce)" if world > 1 else "single GPU"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "knn": knn, "kernels": kernels,
+            "config": {"workload": leg["workload"],
+                       "parallelism": f"dp{world} (one batch per rank, flat-buffer gradient all-reduce)"
+                                      if world > 1 else "single GPU",
+                       "batch_assembly_ms": None if leg["batch_assembly_ms"] is None
+                       else round(leg["batch_assembly_ms"], 3)},
+            "roofline": leg["roofline"], "roofline_next": leg["roofline_next"], "cpu_baseline": cpu_baseline,
+            "entity_level": entity, "knn": knn, "kernels": leg["kernels"],
         }
         print(json.dumps(out))
     if world > 1:
@@ -293,18 +370,33 @@ def knn_leg(args, world, rank, dev):
 
 
 def cpu_gat_baseline(args, n_dim, e_dim, hidden, layers):
-    """Torch-CPU restatement of the reference's DGL path (the oracle), same recipe, on a 1/10
-    scale graph of the same shape family."""
+    """Torch-CPU restatement of the reference's DGL path (the oracle), same recipe, on a bounded
+    sample of the workload: a batch of 2 (of the 12) StreamSpot-sized graphs, or a 1/10 scale graph
+    of the same shape family for the full-graph workloads."""
     from magic_amd import synth
     from oracle import gat_oracle as O
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
     torch.set_num_threads(cores)
-    n0, e0 = synth.SHAPES[args.workload][:2]
-    scale = 0.1 * args.scale
-    n, e = max(64, int(n0 * scale)), max(64, int(e0 * scale))
-    g = synth.make_graph(n, e, n_dim, e_dim, seed=1004)
-    og = O.OGraph(g.edges()[0], g.edges()[1], n)
-    og.edata["attr"] = g.edata["attr"]
+    if args.workload == "streamspot_batch":
+        n0, e0 = synth.SHAPES["streamspot"][:2]
+        n1, e1 = max(64, int(n0 * args.scale)), max(64, int(e0 * args.scale))
+        parts = [synth.make_graph(n1, e1, n_dim, e_dim, seed=1002 + i) for i in range(2)]
+        src = torch.cat([p_.edges()[0] + i * n1 for i, p_ in enumerate(parts)])
+        dst = torch.cat([p_.edges()[1] + i * n1 for i, p_ in enumerate(parts)])
+        ntype = torch.cat([p_.ndata["type"] for p_ in parts])
+        e_attr = torch.cat([p_.edata["attr"] for p_ in parts])
+        n, e = 2 * n1, int(src.numel())
+        what = f"a batch of 2 StreamSpot-sized graphs (N={n}, E={e}; the GPU step takes 12)"
+    else:
+        n0, e0 = synth.SHAPES[args.workload][:2]
+        scale = 0.1 * args.scale
+        n, e = max(64, int(n0 * scale)), max(64, int(e0 * scale))
+        g = synth.make_graph(n, e, n_dim, e_dim, seed=1004)
+        src, dst = g.edges()
+        ntype, e_attr = g.ndata["type"], g.edata["attr"]
+        what = f"a {args.workload}-shaped graph at 1/10 scale (N={n}, E={e})"
+    og = O.OGraph(src, dst, n)
+    og.edata["attr"] = e_attr
     torch.manual_seed(0)
     model = O.build_model(n_dim, e_dim, hidden, layers)
     model.train()
@@ -312,7 +404,7 @@ def cpu_gat_baseline(args, n_dim, e_dim, hidden, layers):
     thr = min(10000, n)
 
     def step():
-        og.ndata["attr"] = torch.nn.functional.one_hot(g.ndata["type"], n_dim).float()
+        og.ndata["attr"] = torch.nn.functional.one_hot(ntype, n_dim).float()
         neg = O.uniform_negative_pairs(og, thr, seed=1)
         loss = model.compute_loss(og, neg_pairs=neg, pos_idx=random.sample(range(e), thr))
         opt.zero_grad()
@@ -326,8 +418,8 @@ def cpu_gat_baseline(args, n_dim, e_dim, hidden, layers):
         reps += 1
     dt = time.perf_counter() - t0
     return {"value": round(e * reps / dt, 1), "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": f"torch-CPU restatement of the DGL path (oracle/gat_oracle.py), same recipe on a "
-                      f"{args.workload}-shaped graph at 1/10 scale (N={n}, E={e}), {reps} steps"}
+            "sample": f"torch-CPU restatement of the DGL path (oracle/gat_oracle.py), same recipe on {what}, "
+                      f"{reps} steps"}
 
 
 def cpu_knn_baseline(args):

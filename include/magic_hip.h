@@ -108,7 +108,9 @@ int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_scor
                    const uint8_t *x_mask /* [N,in_dim] dropout keep mask applied to x, or NULL */, float x_scale,
                    const float *w /* [C+n_score+res_c, in_dim] */,
                    float *hs, int64_t ld_hs, float *score, float *res, int64_t ld_res,
-                   void *stream);
+                   void *workspace /* may be NULL: the wide-layer kernel keeps the split weight there */,
+                   size_t workspace_bytes, void *stream);
+size_t magic_proj_fwd_workspace_bytes(int32_t in_dim, int32_t out_total /* out_c + n_score + res_c */);
 
 /* Backward of magic_proj_fwd (the adjoints torch autograd forms for nn.Linear at
  * model/gat.py:284,:323 and model/autoencoder.py:237, and for nn.Dropout at model/gat.py:283

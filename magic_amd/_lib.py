@@ -36,7 +36,8 @@ SYMBOLS = {
     "magic_csr_build_workspace_bytes": (c_i32, [c_i64, c_i64, C.POINTER(c_sz)]),
     "magic_csr_build": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_proj_fwd": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_i64,
-                               c_vp, c_vp, c_i64, c_vp]),
+                               c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "magic_proj_fwd_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "magic_proj_bwd_input_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
     "magic_proj_bwd_input": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "magic_proj_bwd_weight_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
@@ -215,9 +216,10 @@ def proj_fwd(x: torch.Tensor, w: torch.Tensor, out_c: int, n_score: int, res_c: 
     hs = torch.empty(N, out_c, dtype=torch.float32, device=dev)
     score = torch.empty(N, n_score, dtype=torch.float32, device=dev) if n_score else None
     res = torch.empty(N, res_c, dtype=torch.float32, device=dev) if res_c else None
+    ws = workspace(lib.magic_proj_fwd_workspace_bytes(F, out_c + n_score + res_c), dev)
     _check(lib.magic_proj_fwd(N, F, out_c, n_score, res_c, _dev(x, torch.float32, "x"), x.stride(0),
                               _dev(x_mask), float(x_scale), _dev(w, torch.float32, "w"), _dev(hs), out_c,
-                              _dev(score), _dev(res), res_c, _stream()), "magic_proj_fwd")
+                              _dev(score), _dev(res), res_c, ws.data_ptr(), ws.numel(), _stream()), "magic_proj_fwd")
     return hs, score, res
 
 
@@ -251,7 +253,7 @@ def proj_bwd_input(dy: torch.Tensor, w: torch.Tensor, add: Optional[torch.Tensor
         assert act_pre.is_contiguous() and act_pre.shape == (N, F)
     ep.act_pre, ep.prelu_w = _dev(act_pre), _dev(prelu_w)
     ep.col_sum, ep.prelu_grad = _dev(col_sum), _dev(prelu_grad)
-    nbytes = lib.magic_proj_bwd_input_workspace_bytes(N, K, F) if want_col_sum else 256
+    nbytes = lib.magic_proj_bwd_input_workspace_bytes(N, K, F)
     ws = workspace(nbytes, dev)
     _check(lib.magic_proj_bwd_input(N, K, F, _dev(dy, torch.float32, "dy"), dy.stride(0),
                                     _dev(w, torch.float32, "w"), C.byref(ep), _dev(dx), dx.stride(0),

@@ -48,6 +48,7 @@ struct Arena {
         return r;
     }
     bool ok() const { return off <= cap; }
+    bool fits(size_t bytes) const { return base != nullptr && off <= cap && off + align_up(bytes) <= cap; }
 };
 
 // grid for a grid-stride kernel: enough blocks to fill 256 CUs x 8, never more than needed

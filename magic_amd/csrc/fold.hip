@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void k_fold_fwd(FoldArgs a) {
             } else if (r < Cp + 2 * H) {
                 const int h = (r - Cp) % H;
                 const float *at = (r - Cp) < H ? a.attn_h : a.attn_t;
+#pragma unroll 8
                 for (int d = 0; d < D; ++d) v = fmaf(at[h * D + d], a.w_fc[(h * D + d) * F + k], v);
             } else {
                 const int q = r - Cp - 2 * H, h = q / Dp, d = q % Dp;
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void k_fold_fwd(FoldArgs a) {
         } else if (i < n_aug + n_tab) {
             const int j = i - n_aug, t = j / H, h = j % H;
             float v = 0.f;
+#pragma unroll 8
             for (int d = 0; d < D; ++d) v = fmaf(a.attn_e[h * D + d], a.w_efc[(h * D + d) * a.e_dim + t], v);
             a.table[j] = v;
         } else {
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void k_fold_bwd(FoldArgs a) {
     const float *dt = a.d_w_aug + (int64_t)(Cp + H) * F;  // [H,F]
     const int n_fc = C * F, n_res = a.has_res ? C * F : 0, n_efc = C * a.e_dim;
     const int n_vec = C;  // attn_h, attn_t, attn_e, bias: C entries each
-    const int total = n_fc + n_res + n_efc + 3 * n_vec + (a.has_bias ? n_vec : 0);
+    const int total = n_fc + n_res + n_efc + (a.has_bias ? n_vec : 0);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         int j = i;
         if (j < n_fc) {
@@ -81,23 +83,25 @@ __global__ __launch_bounds__(256) void k_fold_bwd(FoldArgs a) {
             continue;
         }
         j -= n_efc;
-        const int which = j / n_vec, c = j % n_vec, h = c / D, d = c % D;
+        const int h = j / D, d = j % D;
+        a.d_bias[j] = a.d_bias_p ? a.d_bias_p[h * Dp + d] : 0.f;
+    }
+    // the attention-vector gradients are dot products over F (or e_dim): one wave each, lanes
+    // stride over the reduction index, fixed butterfly at the end
+    const int lane = threadIdx.x & 63;
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < 3 * n_vec; q += gridDim.x * 4) {
+        const int which = q / n_vec, c = q % n_vec, h = c / D;
         float v = 0.f;
-        if (which == 0) {
+        if (which < 2) {
+            const float *g = which == 0 ? dh : dt;
             if (a.d_w_aug)
-                for (int k = 0; k < F; ++k) v = fmaf(a.w_fc[c * F + k], dh[h * F + k], v);
-            a.d_attn_h[c] = v;
-        } else if (which == 1) {
-            if (a.d_w_aug)
-                for (int k = 0; k < F; ++k) v = fmaf(a.w_fc[c * F + k], dt[h * F + k], v);
-            a.d_attn_t[c] = v;
-        } else if (which == 2) {
-            if (a.d_table)
-                for (int t = 0; t < a.e_dim; ++t) v = fmaf(a.w_efc[c * a.e_dim + t], a.d_table[t * H + h], v);
-            a.d_attn_e[c] = v;
-        } else {
-            a.d_bias[c] = a.d_bias_p ? a.d_bias_p[h * Dp + d] : 0.f;
+                for (int k = lane; k < F; k += 64) v = fmaf(a.w_fc[c * F + k], g[h * F + k], v);
+        } else if (a.d_table) {
+            for (int t = lane; t < a.e_dim; t += 64) v = fmaf(a.w_efc[c * a.e_dim + t], a.d_table[t * H + h], v);
         }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) (which == 0 ? a.d_attn_h : which == 1 ? a.d_attn_t : a.d_attn_e)[c] = v;
     }
 }
 
@@ -140,7 +144,10 @@ int magic_fold_bwd(int32_t H, int32_t D, int32_t Dp, int32_t F, int32_t e_dim, c
     a.d_attn_e = d_attn_e, a.d_bias = d_bias;
     const int C = H * D;
     const int64_t n = (int64_t)C * F * (a.has_res ? 2 : 1) + (int64_t)C * e_dim + (int64_t)C * (a.has_bias ? 4 : 3);
-    MAGIC_LAUNCH("fold_bwd", k_fold_bwd, magic::stride_grid(n, 256, 1024), 256, 0, (hipStream_t)stream_, a);
+    int grid = magic::stride_grid(n, 256, 1024);
+    const int dot_blocks = (3 * C + 3) / 4;  // one wave per dot product
+    if (grid < dot_blocks) grid = dot_blocks < 1024 ? dot_blocks : 1024;
+    MAGIC_LAUNCH("fold_bwd", k_fold_bwd, grid, 256, 0, (hipStream_t)stream_, a);
     return magic::launch_status();
 }
 

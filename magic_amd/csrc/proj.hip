@@ -20,7 +20,8 @@
 
 namespace magic {
 int proj_rows_try(const ProjArgs &a, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream);
-int proj_gemm_try(const ProjArgs &a, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream);
+int proj_gemm_try(const ProjArgs &a, void *planes_ws, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream);
+size_t proj_gemm_workspace_bytes(int F, int M);
 }
 
 namespace {
@@ -458,10 +459,10 @@ int64_t n_partials(const ProjArgs &a, int nct) {
 }
 
 // up to 10 column tiles (320 outputs) per launch; wider outputs take several launches of 8
-int dispatch(const ProjArgs &a0, hipStream_t stream) {
+int dispatch(const ProjArgs &a0, void *gemm_ws, hipStream_t stream) {
     ProjArgs a = a0;
     a.col0 = 0;
-    const int st_gemm = magic::proj_gemm_try(a, nullptr, nullptr, false, stream);
+    const int st_gemm = magic::proj_gemm_try(a, gemm_ws, nullptr, nullptr, false, stream);
     if (st_gemm != MAGIC_ERR_UNSUPPORTED) return st_gemm;
     const int st_rows = magic::proj_rows_try(a, nullptr, nullptr, false, stream);
     if (st_rows != MAGIC_ERR_UNSUPPORTED) return st_rows;
@@ -507,7 +508,7 @@ extern "C" {
 
 int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_score, int32_t res_c, const float *x,
                    int64_t ld_x, const uint8_t *x_mask, float x_scale, const float *w, float *hs, int64_t ld_hs,
-                   float *score, float *res, int64_t ld_res, void *stream_) {
+                   float *score, float *res, int64_t ld_res, void *workspace, size_t workspace_bytes, void *stream_) {
     if (n_rows < 0 || in_dim <= 0 || out_c <= 0 || n_score < 0 || res_c < 0) return MAGIC_ERR_INVALID_ARG;
     if (n_rows == 0) return MAGIC_OK;
     if (!x || !w || !hs || ld_x < in_dim || ld_hs < out_c) return MAGIC_ERR_INVALID_ARG;
@@ -533,7 +534,15 @@ int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_scor
     a.score = score;
     a.res = res;
     a.ld_res = ld_res;
-    return dispatch(a, (hipStream_t)stream_);
+    // the block-tiled kernel keeps the split weight in the workspace; without one the other kernels run
+    const size_t need = magic::proj_gemm_workspace_bytes(a.F, a.M);
+    void *gemm_ws = (need && workspace && workspace_bytes >= need) ? workspace : nullptr;
+    return dispatch(a, gemm_ws, (hipStream_t)stream_);
+}
+
+size_t magic_proj_fwd_workspace_bytes(int32_t in_dim, int32_t out_total) {
+    if (in_dim <= 0 || out_total <= 0) return 256;
+    return magic::proj_gemm_workspace_bytes(in_dim, out_total) + 256;
 }
 
 size_t magic_proj_bwd_input_workspace_bytes(int64_t n_rows, int32_t k_dim, int32_t out_dim) {
@@ -542,7 +551,8 @@ size_t magic_proj_bwd_input_workspace_bytes(int64_t n_rows, int32_t k_dim, int32
     int64_t np = ((n_rows + BM - 1) / BM) * 4;
     if (np < 4096) np = 4096;
     const size_t windows = (size_t)(out_dim + 63) / 64;  // part_prelu holds one row per 64-column window
-    return magic::align_up((size_t)np * out_dim * sizeof(float)) + magic::align_up((size_t)np * windows * sizeof(float)) + 256;
+    return magic::align_up((size_t)np * out_dim * sizeof(float)) + magic::align_up((size_t)np * windows * sizeof(float)) +
+           magic::proj_gemm_workspace_bytes(k_dim, out_dim) + 256;
 }
 
 int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim, const float *dy, int64_t ld_dy,
@@ -583,21 +593,24 @@ int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim, const f
     }
     int64_t np = 0;
     int n_win = 1;
+    magic::Arena ar(workspace, workspace_bytes);
+    void *gemm_ws = nullptr;
+    const size_t need = magic::proj_gemm_workspace_bytes(a.F, a.M);
+    if (need && ar.fits(need)) gemm_ws = ar.take<unsigned char>(need);
     if (sums) {
         const int tiles = (out_dim + 31) / 32;
         a.part_col = static_cast<float *>(workspace);  // provisional: the kernel choice looks at it
-        if (magic::proj_gemm_try(a, &np, &n_win, true, stream) != MAGIC_OK &&
+        if ((!gemm_ws || magic::proj_gemm_try(a, gemm_ws, &np, &n_win, true, stream) != MAGIC_OK) &&
             magic::proj_rows_try(a, &np, &n_win, true, stream) != MAGIC_OK) {
             if (tiles > 10) return MAGIC_ERR_UNSUPPORTED;  // column sums need a single launch there
             np = n_partials(a, tiles);
             n_win = 1;
         }
-        magic::Arena ar(workspace, workspace_bytes);
         a.part_col = ar.take<float>((size_t)np * out_dim);
         a.part_prelu = ar.take<float>((size_t)np * n_win);
         if (!ar.ok() || !a.part_col || !a.part_prelu) return MAGIC_ERR_WORKSPACE;
     }
-    int st = dispatch(a, stream);
+    int st = dispatch(a, gemm_ws, stream);
     if (st != MAGIC_OK) return st;
     if (sums) {
         MAGIC_LAUNCH("proj_bwd_input_sums", k_proj_sums, out_dim + 1, 256, 0, stream, a.part_col, a.part_prelu, (int)np,

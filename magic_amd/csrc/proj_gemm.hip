@@ -4,10 +4,13 @@
 //
 //  * 128 x 128 output tile per block of four waves (2 x 2, 64 x 64 per wave = 2 x 2 MFMA tiles),
 //    K in steps of 32.
-//  * split-bf16 products (bf16_split.h): both operand tiles are split into their three bf16
-//    planes once, when they are staged in LDS, and every wave reads its MFMA operands from
-//    there as 16-byte fragments -- the split costs (M/128 + N/128) / 2 VALU passes per element
-//    instead of one per MFMA tile, and 6 bf16 MFMAs replace 8 fp32 MFMAs of twice their length.
+//  * split-bf16 products (bf16_split.h).  The weight is split once per call by a small pre-pass
+//    into its three bf16 planes, stored tile by tile ([column block][K step][plane][128][32], zero
+//    padded) in the caller's workspace; the main kernel copies one 24 KB tile image per K step
+//    into LDS with 16-byte loads and stores, no arithmetic.  The X tile is split when it is
+//    staged (coalesced 128-byte row segments; a lane-owns-row load pattern as in proj_rows.hip
+//    makes the texture addresser the bottleneck at this arithmetic intensity), once per column
+//    block instead of once per MFMA tile.
 //  * one LDS buffer, register prefetch: the X loads of step k+2 and the W loads of step k+1 are
 //    issued before the MFMAs of step k and land in registers while those run; two resident blocks
 //    per CU overlap one block's staging with the other's MFMAs.
@@ -32,12 +35,17 @@ constexpr int GLD = GBK + 8;       // bf16 per staged row
 constexpr int PLANE = 128 * GLD;   // bf16 per plane of one operand tile
 constexpr size_t GEMM_LDS = (size_t)2 * 3 * PLANE * 2;
 constexpr int LDO = 64 + 4;        // strip row stride (floats)
+constexpr int TILE_ELEMS = 3 * GBN * GBK;  // bf16 per weight tile image in the workspace
+
+typedef float vec4_t __attribute__((ext_vector_type(4)));  // 16-byte register quad (plain vector: stays in VGPRs)
 
 struct GemmPlan {
     int col_blocks;
     int64_t row_blocks;
     int64_t per_xcd;  // blocks per XCD (grid = 8 * per_xcd)
     int n_win;        // 64-column windows that hold output columns
+    int nk;
+    const __bf16 *planes;  // [col_blocks][nk][3][128][32]
 };
 
 union Pack4 {
@@ -55,16 +63,27 @@ __device__ __forceinline__ void stage4(__bf16 *dst, float4 v) {
     *reinterpret_cast<uint2 *>(dst + 2 * PLANE) = p3.u;
 }
 
-// four consecutive tile rows (output columns) at one k -> the three planes, element by element
-__device__ __forceinline__ void stage4_t(__bf16 *dst, float4 v) {
-    bf16x2_t a1, a2, a3, b1, b2, b3;
-    split2(f32x2_t{v.x, v.y}, a1, a2, a3);
-    split2(f32x2_t{v.z, v.w}, b1, b2, b3);
-    dst[0] = a1[0], dst[GLD] = a1[1], dst[2 * GLD] = b1[0], dst[3 * GLD] = b1[1];
-    dst += PLANE;
-    dst[0] = a2[0], dst[GLD] = a2[1], dst[2 * GLD] = b2[0], dst[3 * GLD] = b2[1];
-    dst += PLANE;
-    dst[0] = a3[0], dst[GLD] = a3[1], dst[2 * GLD] = b3[0], dst[3 * GLD] = b3[1];
+// weight -> tile images of its three bf16 planes (two consecutive k per thread)
+__global__ __launch_bounds__(256) void k_gemm_split_w(ProjArgs a, int col_blocks, int nk, __bf16 *planes) {
+    const int64_t total = (int64_t)col_blocks * nk * GBN * (GBK / 2);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k2 = (int)(i % (GBK / 2));
+        const int row = (int)((i / (GBK / 2)) % GBN);
+        const int64_t tile = i / ((GBK / 2) * GBN);   // cb * nk + kb
+        const int kb = (int)(tile % nk), cb = (int)(tile / nk);
+        const int col = cb * GBN + row, k = kb * GBK + 2 * k2;
+        f32x2_t v = {0.f, 0.f};
+        if (col < a.M) {
+            if (k < a.F) v[0] = a.w[(int64_t)col * a.w_rs + (int64_t)k * a.w_cs];
+            if (k + 1 < a.F) v[1] = a.w[(int64_t)col * a.w_rs + (int64_t)(k + 1) * a.w_cs];
+        }
+        bf16x2_t h1, h2, h3;
+        split2(v, h1, h2, h3);
+        __bf16 *d = planes + tile * TILE_ELEMS + row * GBK + 2 * k2;
+        *reinterpret_cast<bf16x2_t *>(d) = h1;
+        *reinterpret_cast<bf16x2_t *>(d + GBN * GBK) = h2;
+        *reinterpret_cast<bf16x2_t *>(d + 2 * GBN * GBK) = h3;
+    }
 }
 
 template <bool EP>
@@ -82,7 +101,6 @@ __global__ __launch_bounds__(256, 2) void k_proj_gemm(ProjArgs a, GemmPlan p) {
     const int64_t rb = pid / p.col_blocks;
     const int64_t row0 = rb * GBM;
     const int colb = cb * GBN;
-    const bool nt = a.w_cs == 1;  // weight rows are output columns (forward); else stored [k][column]
 
     float16_t acc[2][2];
 #pragma unroll
@@ -110,28 +128,14 @@ __global__ __launch_bounds__(256, 2) void k_proj_gemm(ProjArgs a, GemmPlan p) {
             if (a.x_mask) rm[j] = *reinterpret_cast<const uint32_t *>(a.x_mask + rc * a.F + kc);
         }
     };
-    auto load_w = [&](int kb, float4 (&rw)[4]) {
-        if (nt) {
-            const int k = kb * GBK + sk;
-            const int kc = k < a.F ? k : 0;
+    // weight tile image: 1536 16-byte pieces, six per thread; piece c = (plane, row, quarter row)
+    const __bf16 *tiles = p.planes + (int64_t)cb * p.nk * TILE_ELEMS;
+    auto load_w = [&](int kb, vec4_t (&rw)[6]) {
+        const vec4_t *src = reinterpret_cast<const vec4_t *>(tiles + (int64_t)kb * TILE_ELEMS);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = colb + sr + 32 * j;
-                const int cc = c < a.M ? c : a.M - 1;
-                rw[j] = *reinterpret_cast<const float4 *>(a.w + (int64_t)cc * a.w_rs + kc);
-            }
-        } else {  // one k per thread row, four consecutive columns per thread
-            const int kk = kb * GBK + sr;
-            const int kkc = kk < a.F ? kk : 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = colb + sk + 32 * j;
-                const int cc = c < a.M ? c : 0;
-                rw[j] = *reinterpret_cast<const float4 *>(a.w + (int64_t)kkc * a.w_cs + cc);
-            }
-        }
+        for (int j = 0; j < 6; ++j) rw[j] = src[tid + 256 * j];
     };
-    auto store_tiles = [&](int kb, const float4 (&ra)[4], const uint32_t (&rm)[4], const float4 (&rw)[4]) {
+    auto store_tiles = [&](int kb, const float4 (&ra)[4], const uint32_t (&rm)[4], const vec4_t (&rw)[6]) {
         const int k = kb * GBK + sk;
         const bool kok = k < a.F;
 #pragma unroll
@@ -146,21 +150,11 @@ __global__ __launch_bounds__(256, 2) void k_proj_gemm(ProjArgs a, GemmPlan p) {
             if (!kok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             stage4(sA + (sr + 32 * j) * GLD + sk, v);
         }
-        if (nt) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float4 v = rw[j];
-                if (!kok || colb + sr + 32 * j >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                stage4(sB + (sr + 32 * j) * GLD + sk, v);
-            }
-        } else {
-            const bool kkok = kb * GBK + sr < a.F;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float4 v = rw[j];
-                if (!kkok || colb + sk + 32 * j >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                stage4_t(sB + (sk + 32 * j) * GLD + sr, v);
-            }
+        for (int j = 0; j < 6; ++j) {
+            const int c = tid + 256 * j;
+            const int pr = c >> 2, part = c & 3;  // pr = plane * 128 + row
+            *reinterpret_cast<vec4_t *>(sB + pr * GLD + part * 8) = rw[j];
         }
     };
     auto mfma_step = [&]() {
@@ -192,8 +186,9 @@ __global__ __launch_bounds__(256, 2) void k_proj_gemm(ProjArgs a, GemmPlan p) {
     };
 
     // X tiles are prefetched two K steps ahead (HBM latency), W tiles one (they come out of L2)
-    const int nk = (a.F + GBK - 1) / GBK;
-    float4 ra0[4], ra1[4], rw[4];
+    const int nk = p.nk;
+    float4 ra0[4], ra1[4];
+    vec4_t rw[6];
     uint32_t rm0[4], rm1[4];
     load_a(0, ra0, rm0);
     load_w(0, rw);
@@ -280,22 +275,27 @@ template <bool EP> int launch(const ProjArgs &a, const GemmPlan &p, hipStream_t 
     return magic::launch_status();
 }
 
+bool gemm_shape(int F, int M) { return F >= 96 && M >= 128; }
+
 }  // namespace
 
 namespace magic {
 
-// Runs the projection on the block-tiled kernel when it is a GEMM (wide K and M) and the operand
-// alignment allows it; MAGIC_ERR_UNSUPPORTED otherwise.  `n_part` / `n_win` describe the partial
-// sums an epilogue launch writes: part_col [n_part, C], part_prelu [n_win, n_part].
-int proj_gemm_try(const ProjArgs &a, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream) {
-    if (a.n <= 0 || a.F < 96 || a.M < 128 || a.col0 != 0) return MAGIC_ERR_UNSUPPORTED;
+// bytes of workspace the block-tiled kernel needs for the split weight (0: shape not served)
+size_t proj_gemm_workspace_bytes(int F, int M) {
+    if (!gemm_shape(F, M)) return 0;
+    const size_t cbs = (M + GBN - 1) / GBN, nk = (F + GBK - 1) / GBK;
+    return align_up(cbs * nk * TILE_ELEMS * 2);
+}
+
+// Runs the projection on the block-tiled kernel when it is a GEMM (wide K and M), the operand
+// alignment allows it and `planes_ws` (proj_gemm_workspace_bytes) is given; MAGIC_ERR_UNSUPPORTED
+// otherwise.  `n_part` / `n_win` describe the partial sums an epilogue launch writes:
+// part_col [n_part, C], part_prelu [n_win, n_part].
+int proj_gemm_try(const ProjArgs &a, void *planes_ws, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream) {
+    if (a.n <= 0 || !gemm_shape(a.F, a.M) || a.col0 != 0) return MAGIC_ERR_UNSUPPORTED;
     if ((a.F & 3) || !aligned16(a.x, a.ld_x)) return MAGIC_ERR_UNSUPPORTED;
     if (a.x_mask && ((uintptr_t)a.x_mask & 3)) return MAGIC_ERR_UNSUPPORTED;
-    if (a.w_cs == 1) {
-        if (!aligned16(a.w, a.w_rs)) return MAGIC_ERR_UNSUPPORTED;
-    } else {
-        if (a.w_rs != 1 || (a.M & 3) || !aligned16(a.w, a.w_cs)) return MAGIC_ERR_UNSUPPORTED;
-    }
     const bool ep = has_epilogue(a);
     if (ep) {
         if (a.M != a.C || (a.C & 3) || !aligned16(a.hs, a.ld_hs)) return MAGIC_ERR_UNSUPPORTED;
@@ -307,6 +307,7 @@ int proj_gemm_try(const ProjArgs &a, int64_t *n_part, int *n_win, bool dry_run, 
     }
     GemmPlan p;
     p.col_blocks = (a.M + GBN - 1) / GBN;
+    p.nk = (a.F + GBK - 1) / GBK;
     p.row_blocks = (a.n + GBM - 1) / GBM;
     const int64_t blocks = p.row_blocks * p.col_blocks;
     p.per_xcd = (blocks + 7) / 8;
@@ -315,6 +316,11 @@ int proj_gemm_try(const ProjArgs &a, int64_t *n_part, int *n_win, bool dry_run, 
     if (n_part) *n_part = p.row_blocks * 2;
     if (n_win) *n_win = p.n_win;
     if (dry_run) return MAGIC_OK;
+    if (!planes_ws || ((uintptr_t)planes_ws & 15)) return MAGIC_ERR_UNSUPPORTED;
+    p.planes = static_cast<const __bf16 *>(planes_ws);
+    const int64_t pairs = (int64_t)p.col_blocks * p.nk * GBN * (GBK / 2);
+    MAGIC_LAUNCH("proj_split_weight", k_gemm_split_w, stride_grid(pairs, 256, 1024), 256, 0, stream, a, p.col_blocks,
+                 p.nk, static_cast<__bf16 *>(planes_ws));
     return ep ? launch<true>(a, p, stream) : launch<false>(a, p, stream);
 }
 

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Build profiles/traffic.json and profiles/r01_pmc_summary.txt from two rocprofv3 --pmc passes
-(FETCH_SIZE in one run, WRITE_SIZE in another) over `bench.py --steps 2 --warmup 1`.
+"""Build profiles/traffic.json and profiles/r01_pmc_summary_<workload>.txt from two rocprofv3 --pmc
+passes (FETCH_SIZE in one run, WRITE_SIZE in another) over `bench.py --steps 2 --warmup 1`.
 
 HBM bytes per launch = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB.  The factor 2 on the read side is the
 gfx950 correction for 16-byte-per-lane loads (FETCH_SIZE tallies 128-byte requests at 64 bytes);
 it is re-checked on every run against a kernel of this library whose byte count is known exactly:
-gat_bwd_node_adjoint<4,4> streams two [N, 64] fp32 operands with float4 loads and writes one.
-usage: make_traffic.py <pmc_rd_dir> <pmc_wr_dir> <workload> <n_nodes>
+gat_bwd_node_adjoint<4,LPH> streams two [N, 16*LPH] fp32 operands with float4 loads and writes one.
+usage: make_traffic.py <pmc_rd_dir> <pmc_wr_dir> <workload> <n_nodes> <n_encoder_layers>
 """
 import glob
 import json
@@ -22,6 +22,7 @@ BENCH_NAME = {"k_fwd_light": "gat_fwd_light", "k_bwd_src_light": "gat_bwd_src_li
 
 def main():
     rd_dir, wr_dir, workload, n_nodes = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    n_enc = int(sys.argv[5]) if len(sys.argv) > 5 else 3
     rd = {}
     for f in glob.glob(os.path.join(rd_dir, "**", "*counter_collection.csv"), recursive=True):
         for k, v in summarise(f).items():
@@ -33,10 +34,12 @@ def main():
             if "WRITE_SIZE" in v:
                 wr[k] = v["WRITE_SIZE"]
     lines = []
-    cal = rd.get("k_bwd_node_adjoint<4, 4>")
+    cal_key = next((k for k in rd if k.startswith("k_bwd_node_adjoint<4,")), None)
+    cal = rd.get(cal_key) if cal_key else None
     if cal:
-        exact = 2 * n_nodes * 64 * 4 / 1024
-        lines.append(f"# calibration: gat_bwd_node_adjoint<4,4> reads exactly {exact:.0f} KiB, FETCH_SIZE reports "
+        lph = int(cal_key.split(",")[1].strip(" >"))
+        exact = 2 * n_nodes * 16 * lph * 4 / 1024
+        lines.append(f"# calibration: gat_{cal_key[2:]} reads exactly {exact:.0f} KiB, FETCH_SIZE reports "
                      f"{cal:.0f} KiB -> factor {exact / cal:.3f} (the gfx950 factor 2 for 16-byte-per-lane loads)")
     lines.append(f"{'kernel':44s} {'FETCH KiB':>12s} {'WRITE KiB':>12s} {'HBM MB (2*F+W)':>16s}")
     traffic = {}
@@ -46,13 +49,13 @@ def main():
         lines.append(f"{k:44s} {f:12.0f} {w:12.0f} {total / 1e6:16.1f}")
         traffic[k] = total
     # bench.py reports per name over all layers: launch-weighted mean of the template instances
-    # (three encoder layers <4,LPH> and one decoder layer <1,LPH> per step)
+    # (the encoder layers <4,LPH> and one decoder layer <1,LPH> per step)
     out = {}
     for prefix, name in BENCH_NAME.items():
         enc = [v for k, v in traffic.items() if k.startswith(prefix + "<4")]
         dec = [v for k, v in traffic.items() if k.startswith(prefix + "<1")]
         if enc and dec:
-            out[name] = int((3 * enc[0] + dec[0]) / 4)
+            out[name] = int((n_enc * enc[0] + dec[0]) / (n_enc + 1))
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
     path = os.path.join(root, "traffic.json")
     data = {}
@@ -60,7 +63,7 @@ def main():
         data = json.load(open(path))
     data[workload] = out
     json.dump(data, open(path, "w"), indent=1, sort_keys=True)
-    open(os.path.join(root, "r01_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(root, f"r01_pmc_summary_{workload}.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:3]))
     print(out)
 
