@@ -85,7 +85,9 @@ class ShardedNearestNeighbors:
     reproduces the single-device (distance, index) ordering exactly.
     """
 
-    def __init__(self, n_neighbors: int, group=None, device="cuda"):
+    def __init__(self, n_neighbors: int, group=None, device="cuda", local=None):
+        """``local``: the per-shard searcher (``fit(x)``, ``kneighbors_device(x, k, index_offset)``, a
+        ``_train`` attribute); the HIP search unless a test injects a host one."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -93,7 +95,7 @@ class ShardedNearestNeighbors:
         self.world = dist.get_world_size(group)
         self.k = n_neighbors
         self.device = torch.device(device)
-        self.local = NearestNeighbors(n_neighbors, device=device)
+        self.local = local if local is not None else NearestNeighbors(n_neighbors, device=device)
         self.offset = 0
 
     @staticmethod
@@ -110,6 +112,16 @@ class ShardedNearestNeighbors:
         self.offset = int(offset or 0)
         self.local.fit(x_local)
         return self
+
+    def kneighbors(self, x, n_neighbors: Optional[int] = None, return_distance: bool = True):
+        """scikit-learn's call shape (as ``NearestNeighbors.kneighbors``), so that the sharded search
+        can be handed to ``model.eval.entity_level_distances(..., nbrs=...)``: every rank passes the
+        same replicated queries and gets the same global result."""
+        was_numpy = isinstance(x, np.ndarray)
+        d, i = self.kneighbors_device(_as_device_f32(x, self.device), n_neighbors)
+        if was_numpy:
+            d, i = d.cpu().numpy(), i.cpu().numpy()
+        return (d, i) if return_distance else i
 
     def local_topk(self, xq: torch.Tensor, k: int):
         n_local = self.local._train.shape[0]

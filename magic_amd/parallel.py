@@ -67,3 +67,27 @@ def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None):
 def shard_indices(n_items: int, world: int, rank: int):
     """Round-robin assignment of independent items (graphs) to ranks."""
     return list(range(rank, n_items, world))
+
+
+def embed_graphs(embed_fn, graphs, out_width: int, device, group=None):
+    """Embedding extraction over independent graphs (``eval.py:80-97`` of the reference embeds the
+    train and test graphs one after the other): graph i is embedded by rank ``i % world`` and its
+    ``[N_i, out_width]`` result broadcast from there, so every rank ends with all embeddings, each
+    bit-identical to what a single process computes for that graph.
+
+    ``embed_fn(g) -> [g.num_nodes(), out_width]`` float32 tensor on ``device``."""
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    outs = []
+    for i, g in enumerate(graphs):
+        owner = i % world
+        if owner == rank:
+            emb = embed_fn(g).to(device=device, dtype=torch.float32).contiguous()
+            assert emb.shape == (g.num_nodes(), out_width)
+        else:
+            emb = torch.empty(g.num_nodes(), out_width, dtype=torch.float32, device=device)
+        if multi:
+            dist.broadcast(emb, src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
+        outs.append(emb)
+    return outs

@@ -115,3 +115,89 @@ def test_merge_topk_host_order_rule():
     i = torch.tensor([[[5, 1, 9]], [[2, 7, -1]]])
     md, mi = merge_topk(d, i)
     assert md.tolist() == [[0.0, 0.0, 1.0]] and mi.tolist() == [[2, 5, 1]]
+
+
+class _HostSearch:
+    """Per-shard searcher backed by the numpy oracle (stands in for the HIP search on CPU)."""
+
+    def __init__(self):
+        self._train = None
+
+    def fit(self, x):
+        self._train = torch.as_tensor(np.asarray(x, dtype=np.float32))
+        return self
+
+    def kneighbors_device(self, x, k, index_offset=0):
+        d, i = knn_oracle.exact_topk(self._train.numpy(), np.asarray(x, dtype=np.float32), k)
+        return torch.from_numpy(d), torch.from_numpy(i + index_offset)
+
+    def kneighbors(self, x, n_neighbors):
+        d, i = self.kneighbors_device(x, n_neighbors)
+        return d.numpy(), i.numpy()
+
+
+def _eval_data():
+    rng = np.random.default_rng(11)
+    return (rng.standard_normal((403, 16)).astype(np.float32) * 3 + 1,
+            rng.standard_normal((57, 16)).astype(np.float32) * 3 + 1)
+
+
+def _entity_worker(rank, world, port, out):
+    import random
+    from magic_amd.knn import ShardedNearestNeighbors
+    from magic_amd.model.eval import entity_level_distances
+    _init(rank, world, port)
+    x_train, x_test = _eval_data()
+    random.seed(3)
+    nbrs = ShardedNearestNeighbors(10, device="cpu", local=_HostSearch())
+    mean_distance, distances = entity_level_distances(x_train, x_test, 10, nbrs=nbrs)
+    np.savez(f"{out}/ent{rank}.npz", m=mean_distance, d=distances)
+    dist.destroy_process_group()
+
+
+def test_entity_level_scores_sharded_equal_single_world2(tmp_path):
+    """model/eval.py:282-313 with the train rows sharded over two ranks: same mean distance and
+    same per-row distances as one search over all rows."""
+    import random
+    from magic_amd.model.eval import entity_level_distances
+    port = _free_port()
+    mp.spawn(_entity_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    x_train, x_test = _eval_data()
+    random.seed(3)
+    m, d = entity_level_distances(x_train, x_test, 10, nbrs=_HostSearch())
+    for r in range(2):
+        got = np.load(tmp_path / f"ent{r}.npz")
+        assert float(got["m"]) == float(m)
+        assert np.array_equal(got["d"], d)
+
+
+class _FakeGraph:
+    def __init__(self, n):
+        self.n = n
+
+    def num_nodes(self):
+        return self.n
+
+
+def _embed_worker(rank, world, port, out):
+    from magic_amd.parallel import embed_graphs
+    _init(rank, world, port)
+    graphs = [_FakeGraph(n) for n in (5, 9, 1, 12, 7)]
+    calls = []
+
+    def embed_fn(g):
+        calls.append(g.n)
+        return torch.arange(g.n * 3, dtype=torch.float32).reshape(g.n, 3) * (g.n + 1)
+    outs = embed_graphs(embed_fn, graphs, 3, torch.device("cpu"))
+    torch.save({"outs": outs, "calls": calls}, f"{out}/emb{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_embedding_extraction_round_robin_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_embed_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "emb0.pt"), torch.load(tmp_path / "emb1.pt")
+    assert r0["calls"] == [5, 1, 7] and r1["calls"] == [9, 12]       # graph i on rank i % 2
+    for a, b, n in zip(r0["outs"], r1["outs"], (5, 9, 1, 12, 7)):
+        want = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3) * (n + 1)
+        assert torch.equal(a, want) and torch.equal(b, want)
