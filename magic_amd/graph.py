@@ -25,6 +25,7 @@ by the HIP kernels) lives in a :class:`Structure` that clones share.
 from __future__ import annotations
 
 import contextlib
+import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -184,6 +185,8 @@ class Graph:
         self._batch_num_nodes: Optional[List[int]] = None
         self._batch_num_edges: Optional[List[int]] = None
         self._cache: Dict[str, tuple] = {}
+        # identity of an edata['attr'] tensor known by construction to be one_hot(edata['type'])
+        self._onehot_edge: Optional[tuple] = None
 
     # DGL aliases: srcdata/dstdata are ndata on a homogeneous graph
     @property
@@ -236,6 +239,7 @@ class Graph:
         g._batch_num_nodes = None if self._batch_num_nodes is None else list(self._batch_num_nodes)
         g._batch_num_edges = None if self._batch_num_edges is None else list(self._batch_num_edges)
         g._cache = self._cache  # keyed by tensor identity, safe to share
+        g._onehot_edge = self._onehot_edge
         return g
 
     def to(self, device) -> "Graph":
@@ -260,6 +264,18 @@ class Graph:
         finally:
             self.ndata, self.edata = nd, ed
 
+    def _edge_attr_marked(self) -> bool:
+        """True while ``edata['attr']`` is the very tensor object that was marked, unmodified."""
+        m, attr = self._onehot_edge, self.edata.get("attr")
+        return m is not None and attr is not None and m[0]() is attr and m[1] == attr._version
+
+    def mark_edge_attr_onehot(self):
+        """Declare that ``edata['attr']`` was just built as ``one_hot(edata['type'])``
+        (``utils/loaddata.py:259``): ``edge_types_csc`` then skips its checks, which read results
+        back to the host.  The mark dies with any later write to, or rebinding of, the tensor."""
+        attr = self.edata["attr"]
+        self._onehot_edge = (weakref.ref(attr), attr._version)
+
     # ---- helpers used by the HIP operators -------------------------------------------
     def edge_types_csc(self) -> Optional[torch.Tensor]:
         """Edge type ids (int32) in CSC order when ``edata['attr']`` is the one-hot of an
@@ -272,8 +288,10 @@ class Graph:
         if hit is not None and hit[0] == key:
             return hit[1]
         types = None
-        if attr.dim() == 2 and attr.numel() > 0:
-            t = self.edata.get("type")
+        t = self.edata.get("type")
+        if t is not None and t.numel() == attr.shape[0] and self._edge_attr_marked():
+            types = t.view(-1).long()
+        elif attr.dim() == 2 and attr.numel() > 0:
             if t is not None and t.numel() == attr.shape[0]:
                 t = t.view(-1).long()
                 ok = bool(((t >= 0) & (t < attr.shape[1])).all()) and \
@@ -299,6 +317,27 @@ def graph(data, num_nodes: Optional[int] = None) -> Graph:
     return Graph(src, dst, num_nodes)
 
 
+def _cat_plans(plans, ptr, n_off, e_off) -> SegmentPlan:
+    """Plan of a union graph from the plans of its components: heavy nodes and their chunks keep
+    their order, ids and edge positions shift by the component offsets.  Equal to
+    ``build_segment_plan(ptr)`` element for element, without its size-dependent host round trips."""
+    dev = ptr.device
+    h_off, c_off = [0], [0]
+    for p in plans:
+        h_off.append(h_off[-1] + p.n_heavy)
+        c_off.append(c_off[-1] + p.n_chunks)
+    i32 = torch.int32
+    heavy_node = torch.cat([p.heavy_node + n_off[i] for i, p in enumerate(plans)]).to(i32)
+    heavy_cptr = torch.cat([p.heavy_cptr[:-1] + c_off[i] for i, p in enumerate(plans)] +
+                           [torch.full((1,), c_off[-1], dtype=i32, device=dev)]).to(i32)
+    chunk_node = torch.cat([p.chunk_node + h_off[i] for i, p in enumerate(plans)]).to(i32)
+    chunk_beg = torch.cat([p.chunk_beg + e_off[i] for i, p in enumerate(plans)]).to(i32)
+    chunk_end = torch.cat([p.chunk_end + e_off[i] for i, p in enumerate(plans)]).to(i32)
+    deg = (ptr[1:] - ptr[:-1]).to(torch.int64)
+    order = torch.sort(walk_class(deg), stable=True).indices.to(i32)
+    return SegmentPlan(ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end, order=order)
+
+
 def batch(graphs: Sequence[Graph]) -> Graph:
     """Union graph with node-id offsets (``dgl.batch``, used at ``model/train.py:39``).
 
@@ -318,6 +357,7 @@ def batch(graphs: Sequence[Graph]) -> Graph:
     dst = torch.cat([g._s.dst + n_off[i] for i, g in enumerate(graphs)])
     s = Structure(src, dst, n_off[-1])
     if all(g._s.has_csr() for g in graphs):
+        # no device synchronisation below: every size is already known on the host
         def cat_ptr(attr):
             parts = [getattr(graphs[0]._s, attr)]
             for i, g in enumerate(graphs[1:], 1):
@@ -326,8 +366,11 @@ def batch(graphs: Sequence[Graph]) -> Graph:
 
         def cat_off(attr, offs):
             return torch.cat([getattr(g._s, attr) + offs[i] for i, g in enumerate(graphs)]).to(torch.int32)
-        s.set_csr(cat_ptr("in_ptr"), cat_off("in_src", n_off), cat_off("in_eid", e_off),
-                  cat_ptr("out_ptr"), cat_off("out_dst", n_off), cat_off("out_eid", e_off))
+        s.in_ptr, s.in_src, s.in_eid = cat_ptr("in_ptr"), cat_off("in_src", n_off), cat_off("in_eid", e_off)
+        s.out_ptr, s.out_dst, s.out_eid = cat_ptr("out_ptr"), cat_off("out_dst", n_off), cat_off("out_eid", e_off)
+        s.in_dst, s.out_pos = cat_off("in_dst", n_off), cat_off("out_pos", e_off)
+        s.plan_in = _cat_plans([g._s.plan_in for g in graphs], s.in_ptr, n_off, e_off)
+        s.plan_out = _cat_plans([g._s.plan_out for g in graphs], s.out_ptr, n_off, e_off)
     out = Graph(None, _structure=s)
     for k in graphs[0].ndata:
         if all(k in g.ndata for g in graphs):
@@ -335,6 +378,8 @@ def batch(graphs: Sequence[Graph]) -> Graph:
     for k in graphs[0].edata:
         if all(k in g.edata for g in graphs):
             out.edata[k] = torch.cat([g.edata[k] for g in graphs], 0)
+    if "attr" in out.edata and "type" in out.edata and all(g._edge_attr_marked() for g in graphs):
+        out.mark_edge_attr_onehot()
     out._batch_num_nodes = [g.num_nodes() for g in graphs]
     out._batch_num_edges = [g.num_edges() for g in graphs]
     assert dev == out.device

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..graph import Graph
-from ..utils.utils import create_norm
+from ..utils.utils import create_norm, sample_range
 from .fused import FusedCfg, FusedGMAEFn
 from .gat import GAT, _LinearFn, _pad_head_dim, linear_nobias
 from .loss_func import sce_loss, sce_loss_masked
@@ -37,12 +37,9 @@ def build_model(args):
         mask_rate=args.mask_rate, norm="BatchNorm", loss_fn="sce", alpha_l=args.alpha_l)
 
 
-def global_uniform_negative_sampling(g: Graph, num_samples: int, generator: torch.Generator = None):
-    """At most ``num_samples`` uniformly drawn (src, dst) pairs that are neither edges of ``g``
-    nor self-loops -- the contract of ``dgl.sampling.global_uniform_negative_sampling(g, k)``
-    as called at ``model/autoencoder.py:251`` (one redraw-free trial, so fewer than k pairs may
-    come back).  DGL draws from a private RNG the reference never seeds, so its exact sequence
-    cannot be matched; parity tests inject the pairs instead."""
+def _negative_candidates(g: Graph, num_samples: int, generator: torch.Generator = None):
+    """``num_samples`` uniformly drawn (src, dst) pairs and the mask of those that are neither edges
+    of ``g`` nor self-loops (fixed shapes: nothing is read back to the host)."""
     n = g.num_nodes()
     dev = g.device
     u = torch.randint(0, n, (num_samples,), device=dev, generator=generator)
@@ -52,7 +49,16 @@ def global_uniform_negative_sampling(g: Graph, num_samples: int, generator: torc
     key = u * n + v
     pos = torch.searchsorted(ekey, key).clamp_(max=max(ekey.numel() - 1, 0))
     is_edge = (ekey[pos] == key) if ekey.numel() else torch.zeros_like(key, dtype=torch.bool)
-    ok = (u != v) & ~is_edge
+    return u, v, (u != v) & ~is_edge
+
+
+def global_uniform_negative_sampling(g: Graph, num_samples: int, generator: torch.Generator = None):
+    """At most ``num_samples`` uniformly drawn (src, dst) pairs that are neither edges of ``g``
+    nor self-loops -- the contract of ``dgl.sampling.global_uniform_negative_sampling(g, k)``
+    as called at ``model/autoencoder.py:251`` (one redraw-free trial, so fewer than k pairs may
+    come back).  DGL draws from a private RNG the reference never seeds, so its exact sequence
+    cannot be matched; parity tests inject the pairs instead."""
+    u, v, ok = _negative_candidates(g, num_samples, generator)
     return u[ok], v[ok]
 
 
@@ -104,7 +110,10 @@ class GMAEModel(nn.Module):
 
     def _randperm(self, n, device):
         if self.mask_rng == "cpu":
-            return torch.randperm(n).to(device)       # CPU generator: same stream as a CPU reference run
+            # CPU generator: same stream as a CPU reference run.  Drawn into pinned memory and copied
+            # asynchronously: a pageable copy would make the host wait for everything queued so far
+            pin = torch.device(device).type == "cuda"
+            return torch.randperm(n, pin_memory=pin).to(device, non_blocking=True)
         return torch.randperm(n, device=device)        # model/autoencoder.py:201 on the GPU
 
     def encoding_mask_noise(self, g: Graph, mask_rate=0.3, perm=None):
@@ -190,11 +199,20 @@ class GMAEModel(nn.Module):
         # autoencoder.py:248-256: node pairs of the sampled edge reconstruction (drawn first: the
         # fused chain gathers their hidden rows itself)
         threshold = min(10000, g.num_nodes())
+        neg_valid = None
         if neg_pairs is None:
-            neg_pairs = global_uniform_negative_sampling(g, threshold)
+            # all k candidates go through the head, the rejected ones with weight 0 in the loss: the
+            # same mean over the accepted pairs as selecting them first, without a host round trip
+            # for their count
+            nu, nv, neg_valid = _negative_candidates(g, threshold)
+            neg_pairs = (nu, nv)
         if pos_idx is None:
-            pos_idx = random.sample(range(g.number_of_edges()), threshold)
-        pos_idx = torch.as_tensor(pos_idx, device=g.device).long()
+            pos_idx = sample_range(g.number_of_edges(), threshold)   # = random.sample(range(E), T)
+        pos_idx = torch.as_tensor(pos_idx).long()
+        if pos_idx.device != g.device:
+            if pos_idx.device.type == "cpu" and g.device.type == "cuda":
+                pos_idx = pos_idx.pin_memory()
+            pos_idx = pos_idx.to(g.device, non_blocking=True)
         src, dst = g.edges()
         pos = (src[pos_idx], dst[pos_idx])
         neg = (neg_pairs[0].to(g.device), neg_pairs[1].to(g.device))
@@ -240,7 +258,11 @@ class GMAEModel(nn.Module):
         # autoencoder.py:257-266: sampled edge reconstruction
         y_pred = self._edge_recon(torch.cat([samples[:n_pairs], samples[n_pairs:]], dim=-1)).squeeze(-1)
         y = torch.cat([torch.ones(len(pos[0]), device=g.device), torch.zeros(len(neg[0]), device=g.device)])
-        loss_bce = self.recon_loss(y_pred, y)
+        if neg_valid is None:
+            loss_bce = self.recon_loss(y_pred, y)
+        else:
+            w = torch.cat([torch.ones(len(pos[0]), device=g.device), neg_valid.float()])
+            loss_bce = nn.functional.binary_cross_entropy(y_pred, y, weight=w, reduction="sum") / w.sum()
         loss = loss + loss_bce
         if return_parts:
             return loss, dict(sce=loss_sce, bce=loss_bce, recon=recon, hidden=all_hidden, mask_nodes=mask_nodes)

@@ -40,4 +40,5 @@ def transform_graph(g: Graph, node_feature_dim: int, edge_feature_dim: int) -> G
     new_g = g.clone()
     new_g.ndata["attr"] = F.one_hot(g.ndata["type"].view(-1).long(), num_classes=node_feature_dim).float()
     new_g.edata["attr"] = F.one_hot(g.edata["type"].view(-1).long(), num_classes=edge_feature_dim).float()
+    new_g.mark_edge_attr_onehot()
     return new_g

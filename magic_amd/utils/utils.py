@@ -1,6 +1,7 @@
 """Factories and seeding helpers with the reference's names and behaviour (``utils/utils.py``)."""
 import random
 from functools import partial
+from math import ceil, log
 
 import numpy as np
 import torch
@@ -89,3 +90,47 @@ class NormLayer(nn.Module):
 
     def forward(self, graph, x):
         return self.norm(x)
+
+
+def sample_range(n: int, k: int) -> np.ndarray:
+    """``random.sample(range(n), k)`` (``model/autoencoder.py:253`` draws the positive edges of the
+    reconstruction loss that way) as an int64 array: the same k numbers in the same order, and the
+    ``random`` module's generator left in the same state, computed with array operations.
+
+    CPython picks each element as ``getrandbits(n.bit_length())`` redrawn until it is below n and
+    not yet selected (the set-based branch of ``Random.sample``, taken when n is large against
+    k).  The Mersenne-Twister words are drawn here through numpy from the generator's current state,
+    filtered in bulk, and the state is advanced by exactly the number of words CPython would have
+    consumed.  Small populations, where ``Random.sample`` uses its pool branch, go to it directly.
+    """
+    setsize = 21
+    if k > 5:
+        setsize += 4 ** ceil(log(k * 3, 4))
+    if not (0 < k <= n) or n <= setsize or n.bit_length() > 32:
+        return np.asarray(random.sample(range(n), k), dtype=np.int64)
+    inst = random._inst
+    version, st, gauss = inst.getstate()
+    start = {"bit_generator": "MT19937", "state": {"key": np.array(st[:-1], dtype=np.uint32), "pos": st[-1]}}
+    bg = np.random.MT19937()
+    bg.state = start
+    shift = np.uint64(32 - n.bit_length())
+    chunk = int(k * (1 << n.bit_length()) / n * 1.05) + 64
+    raws = np.empty(0, dtype=np.uint64)
+    while True:
+        raws = np.concatenate([raws, bg.random_raw(chunk)])
+        cand = (raws >> shift).astype(np.int64)
+        pos = np.nonzero(cand < n)[0]
+        vals = cand[pos]
+        _, first = np.unique(vals, return_index=True)   # first occurrence of every value
+        if first.size >= k:
+            first.sort()
+            sel = first[:k]
+            result = vals[sel]
+            consumed = int(pos[sel[-1]]) + 1
+            break
+        chunk = max(64, chunk // 4)
+    bg.state = start
+    bg.random_raw(consumed)
+    end = bg.state["state"]
+    inst.setstate((version, tuple(end["key"].tolist()) + (int(end["pos"]),), gauss))
+    return result

@@ -317,3 +317,21 @@ def test_product_does_not_import_the_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+
+
+def test_sample_range_equals_random_sample():
+    """The array form of random.sample(range(n), k): same numbers, same generator state afterwards."""
+    import random
+
+    from magic_amd.utils.utils import sample_range
+    for n, k, seed in [(2040000, 10000, 0), (170000, 10000, 1), (70000, 10000, 5), (100, 10, 3), (65558, 10000, 2),
+                       (65557, 10000, 2), (3000000, 10000, 9), (2 ** 31 + 5, 1000, 4), (12715, 8407, 6), (40000, 10000, 8)]:
+        random.seed(seed)
+        want = random.sample(range(n), k)
+        after = [random.random(), random.getrandbits(64)]
+        random.seed(seed)
+        got = sample_range(n, k)
+        assert got.tolist() == want
+        assert [random.random(), random.getrandbits(64)] == after
+    with pytest.raises(ValueError):
+        sample_range(5, 6)

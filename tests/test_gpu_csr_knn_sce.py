@@ -42,14 +42,21 @@ def test_batch_csr_equals_direct_sort(cuda):
     from magic_amd.graph import Graph, batch, Structure
     gs = []
     for i in range(5):
-        src, dst, nt, et = small_graph(200 + 37 * i, 900 + 100 * i, 4, 4, seed=100 + i, hub_deg=90)
+        src, dst, nt, et = small_graph(200 + 37 * i, 900 + 100 * i, 4, 4, seed=100 + i, hub_deg=150, hub_out=100)
         g = Graph(torch.from_numpy(src), torch.from_numpy(dst), 200 + 37 * i).to(cuda)
         g.structure.ensure_csr()
         gs.append(g)
     bg = batch(gs)
     direct = Structure(bg.edges()[0], bg.edges()[1], bg.num_nodes()).ensure_csr()
-    for name in ("in_ptr", "in_src", "in_eid", "out_ptr", "out_dst", "out_eid", "out_pos"):
+    for name in ("in_ptr", "in_src", "in_eid", "in_dst", "out_ptr", "out_dst", "out_eid", "out_pos"):
         assert torch.equal(getattr(bg.structure, name), getattr(direct, name)), name
+    # the union's segment plans, assembled from the components' plans, equal the ones built from scratch
+    for which in ("plan_in", "plan_out"):
+        a, b = getattr(bg.structure, which), getattr(direct, which)
+        assert (a.n_heavy, a.n_chunks) == (b.n_heavy, b.n_chunks) and a.n_heavy > 0
+        for name in ("ptr", "heavy_node", "heavy_cptr", "chunk_node", "chunk_beg", "chunk_end", "order"):
+            ta, tb = getattr(a, name), getattr(b, name)
+            assert ta.dtype == tb.dtype and torch.equal(ta, tb), (which, name)
 
 
 @pytest.mark.parametrize("nt,nq,d,k", [(5000, 777, 64, 10), (300, 130, 64, 10), (20000, 300, 64, 200),

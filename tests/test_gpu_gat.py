@@ -280,3 +280,60 @@ def test_embed_on_edgeless_graph(cuda):
         em = mine.embed(g)
     assert em.shape == (n, 64)
     assert rel_err(em, eo) < 1e-5
+
+
+def test_default_sampling_paths_equal_injected_ones(cuda):
+    """compute_loss without injected randomness: (a) the rejected negative candidates carry weight 0
+    in the reconstruction loss instead of being filtered out first -- same loss and gradients as
+    passing the accepted pairs; (b) the positive edges are random.sample(range(E), T), drawn in
+    array form; (c) a batch assembled from marked one-hot attributes takes the type-table path
+    without checking the attribute values."""
+    import random as pyrandom
+    import magic_amd
+    from magic_amd import synth
+    from magic_amd.model.autoencoder import GMAEModel, global_uniform_negative_sampling
+    from magic_amd.utils.loaddata import transform_graph
+    n_dim, e_dim = 8, 20
+    parts = [synth.make_graph(400 + 30 * i, 30000 + 500 * i, n_dim, e_dim, seed=80 + i, attrs=False).to(cuda)
+             for i in range(3)]
+    for g in parts:
+        g.structure.ensure_csr()
+    torch.manual_seed(0)
+    model = GMAEModel(n_dim, e_dim, 64, 2, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(cuda).eval()
+
+    def union():
+        bg = magic_amd.batch([transform_graph(g, n_dim, e_dim) for g in parts])
+        assert bg._edge_attr_marked() and bg.edge_types_csc() is not None
+        return bg
+    bg = union()
+    n, e = bg.num_nodes(), bg.num_edges()
+    thr = min(10000, n)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(5)).to(cuda)
+
+    def grads():
+        out = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+        model.zero_grad(set_to_none=True)
+        return out
+    # default path
+    torch.manual_seed(11)
+    pyrandom.seed(12)
+    with torch.enable_grad():
+        l_def = model.compute_loss(union(), perm=perm)
+    l_def.backward()
+    g_def = grads()
+    # the same choices, injected
+    torch.manual_seed(11)
+    neg = global_uniform_negative_sampling(bg, thr)
+    assert 0 < neg[0].numel() <= thr
+    pyrandom.seed(12)
+    pos = pyrandom.sample(range(e), thr)
+    with torch.enable_grad():
+        l_inj = model.compute_loss(union(), perm=perm, pos_idx=pos, neg_pairs=neg)
+    l_inj.backward()
+    g_inj = grads()
+    assert abs(float(l_def) - float(l_inj)) <= 2e-6 * abs(float(l_inj))
+    assert rel_err(g_def, g_inj) < 1e-4
+    # a write to the attribute tensor drops the mark
+    bg2 = union()
+    bg2.edata["attr"][0, 0] += 0.0
+    assert not bg2._edge_attr_marked()
