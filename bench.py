@@ -90,6 +90,28 @@ def kernel_bytes(kind, N, E_seg, H, C, res):
     raise ValueError(kind)
 
 
+def _stage_collectives_through_host():
+    """Rehearsal mode only: gloo on device tensors of two ranks sharing one GPU does not progress
+    here, so the collectives this file and the package use take a host copy, exchange it, copy back."""
+    real = {k: getattr(dist, k) for k in ("all_reduce", "broadcast", "all_gather_into_tensor")}
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
+        h = t.cpu()
+        real["all_reduce"](h, op=op, group=group)
+        t.copy_(h)
+
+    def broadcast(t, src=0, group=None):
+        h = t.cpu()
+        real["broadcast"](h, src=src, group=group)
+        t.copy_(h)
+
+    def all_gather_into_tensor(out, t, group=None):
+        ho, h = out.cpu(), t.cpu()
+        real["all_gather_into_tensor"](ho, h, group=group)
+        out.copy_(ho)
+    dist.all_reduce, dist.broadcast, dist.all_gather_into_tensor = all_reduce, broadcast, all_gather_into_tensor
+
+
 def dense_work(n, n_dim, hidden, layers, n_pairs):
     """Algorithmic flops (2 per multiply-add) and HBM bytes (fp32 operands and results once, epilogue
     operands not counted) of one step's projection launches, per kernel name."""
@@ -284,11 +306,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rehearsal of the multi-rank path on a one-GPU box: MAGIC_BENCH_REHEARSAL=1 puts every rank on
+    # device 0 and exchanges over gloo (RCCL refuses two ranks on one device); numbers are meaningless
+    rehearsal = os.environ.get("MAGIC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(75, exit=True)   # a stuck rehearsal says where
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+            _stage_collectives_through_host()
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     leg = gat_leg(args, args.workload, args.steps, args.warmup, world, rank, dev)
 
