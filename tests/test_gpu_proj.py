@@ -34,7 +34,7 @@ def _bound(a, b):
     (515, 256, 256, 8, 0, True, True),
     (31, 11, 64, 8, 64, False, False),      # fewer rows than one tile
     (100, 13, 16, 8, 16, True, False),
-    (64, 1024, 256, 0, 0, False, False),    # BLAS route
+    (64, 1024, 256, 0, 0, False, False),    # wide-layer GEMM kernel
 ])
 def test_proj_fwd_against_float64(cuda, n, f, c, ns, rc, mask, strided):
     gen = torch.Generator(device=cuda).manual_seed(n * 7 + f)
@@ -64,9 +64,9 @@ def test_proj_fwd_against_float64(cuda, n, f, c, ns, rc, mask, strided):
     (1000, 72, 64, False),
     (4099, 64, 192, False),    # encoder_to_decoder input gradient
     (700, 18, 64, False),      # decoder
-    (130, 264, 256, True),     # 256-wide model: epilogue in 64-column windows
+    (130, 264, 256, True),     # 256-wide model: wide-layer GEMM kernel with the fused epilogue
     (130, 136, 5, False),      # layer-0 input gradient (narrow output)
-    (77, 256, 1024, False),    # BLAS route
+    (77, 256, 1024, False),    # wide-layer GEMM kernel
 ])
 def test_proj_bwd_input_against_float64(cuda, n, k, f, full):
     gen = torch.Generator(device=cuda).manual_seed(n + k + f)
