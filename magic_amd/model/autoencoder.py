@@ -62,6 +62,22 @@ def global_uniform_negative_sampling(g: Graph, num_samples: int, generator: torc
     return u[ok], v[ok]
 
 
+class _PairRows(torch.autograd.Function):
+    """[2P, W] rows (sources of all pairs, then their destinations) -> [P, 2W] pair matrix
+    (``torch.cat([h[src], h[dst]], dim=-1)``, ``model/autoencoder.py:257-258``).  One copy each way:
+    autograd through two slices and a ``cat`` zero-fills and adds two full-size gradients instead."""
+
+    @staticmethod
+    def forward(ctx, rows, n_pairs):
+        ctx.n_pairs = n_pairs
+        return torch.cat([rows[:n_pairs], rows[n_pairs:]], dim=-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        w = g.shape[1] // 2
+        return torch.cat([g[:, :w], g[:, w:]], dim=0), None
+
+
 class GMAEModel(nn.Module):
     """``model/autoencoder.py:55-305``."""
 
@@ -256,7 +272,7 @@ class GMAEModel(nn.Module):
             loss_sce = sce_loss_masked(recon_p, x_target, mask_nodes, self._alpha_l, n_dim=n_dim)
         loss = loss_sce
         # autoencoder.py:257-266: sampled edge reconstruction
-        y_pred = self._edge_recon(torch.cat([samples[:n_pairs], samples[n_pairs:]], dim=-1)).squeeze(-1)
+        y_pred = self._edge_recon(_PairRows.apply(samples, n_pairs)).squeeze(-1)
         y = torch.cat([torch.ones(len(pos[0]), device=g.device), torch.zeros(len(neg[0]), device=g.device)])
         if neg_valid is None:
             loss_bce = self.recon_loss(y_pred, y)
