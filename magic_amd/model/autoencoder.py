@@ -62,20 +62,37 @@ def global_uniform_negative_sampling(g: Graph, num_samples: int, generator: torc
     return u[ok], v[ok]
 
 
-class _PairRows(torch.autograd.Function):
-    """[2P, W] rows (sources of all pairs, then their destinations) -> [P, 2W] pair matrix
-    (``torch.cat([h[src], h[dst]], dim=-1)``, ``model/autoencoder.py:257-258``).  One copy each way:
-    autograd through two slices and a ``cat`` zero-fills and adds two full-size gradients instead."""
+class _PairLinearFn(torch.autograd.Function):
+    """First layer of the edge-reconstruction head on the pair matrix,
+    ``F.linear(torch.cat([h[src], h[dst]], dim=-1), w, b)`` (``model/autoencoder.py:257-258`` into
+    ``:75``), without forming the pair matrix: ``rows`` holds the P source rows then the P
+    destination rows, and ``[s | d] W^T = s Wa^T + d Wb^T`` with ``W = [Wa | Wb]``.  Backward writes
+    the two halves of the row gradient in place (autograd through slices and ``cat`` zero-fills and
+    adds full-size tensors); the weight gradient runs on the streaming dW kernel."""
 
     @staticmethod
-    def forward(ctx, rows, n_pairs):
+    def forward(ctx, rows, n_pairs, w, b):
+        width = rows.shape[1]
         ctx.n_pairs = n_pairs
-        return torch.cat([rows[:n_pairs], rows[n_pairs:]], dim=-1)
+        ctx.save_for_backward(rows, w)
+        out = torch.addmm(b, rows[:n_pairs], w[:, :width].t())
+        return out.addmm_(rows[n_pairs:], w[:, width:].t())
 
     @staticmethod
     def backward(ctx, g):
-        w = g.shape[1] // 2
-        return torch.cat([g[:, :w], g[:, w:]], dim=0), None
+        rows, w = ctx.saved_tensors
+        n, width = ctx.n_pairs, rows.shape[1]
+        g = g.contiguous()
+        d_rows = d_w = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_rows = torch.empty_like(rows)
+            torch.mm(g, w[:, :width], out=d_rows[:n])
+            torch.mm(g, w[:, width:], out=d_rows[n:])
+        if ctx.needs_input_grad[2]:
+            d_w = torch.cat([_lib.proj_bwd_weight(g, rows[:n]), _lib.proj_bwd_weight(g, rows[n:])], dim=1)
+        if ctx.needs_input_grad[3]:
+            d_b = g.sum(0)
+        return d_rows, None, d_w, d_b
 
 
 class GMAEModel(nn.Module):
@@ -197,12 +214,13 @@ class GMAEModel(nn.Module):
         return FusedCfg(g.structure.ensure_csr(), etype, enc[0].edge_feat, len(enc), H, D, d.out_feat,
                         _pad_head_dim(d.out_feat), enc[0].leaky_relu.negative_slope, res_kinds, masks, scale)
 
-    def _edge_recon(self, pairs):
-        """``edge_recon_fc`` (``model/autoencoder.py:75-78``) with the weight gradients of its two
-        linear layers on the streaming dW kernel (a [rows, features] reduction over ~20k rows that
-        the BLAS heuristics serve badly); everything else stays torch."""
+    def _edge_recon(self, rows, n_pairs):
+        """``edge_recon_fc`` (``model/autoencoder.py:75-78``) on the pairs (row i, row n_pairs + i) of
+        ``rows``, with the weight gradients of its two linear layers on the streaming dW kernel (a
+        [rows, features] reduction over ~20k rows that the BLAS heuristics serve badly); the GEMMs
+        of forward and input gradient stay torch."""
         fc1, act, fc2, sig = self.edge_recon_fc
-        h = act(_LinearFn.apply(pairs, fc1.weight, fc1.bias))
+        h = act(_PairLinearFn.apply(rows, n_pairs, fc1.weight, fc1.bias))
         return sig(_LinearFn.apply(h, fc2.weight, fc2.bias))
 
     def compute_loss(self, g: Graph, perm=None, pos_idx=None, neg_pairs=None, drop_masks=None, return_parts=False,
@@ -272,7 +290,7 @@ class GMAEModel(nn.Module):
             loss_sce = sce_loss_masked(recon_p, x_target, mask_nodes, self._alpha_l, n_dim=n_dim)
         loss = loss_sce
         # autoencoder.py:257-266: sampled edge reconstruction
-        y_pred = self._edge_recon(_PairRows.apply(samples, n_pairs)).squeeze(-1)
+        y_pred = self._edge_recon(samples, n_pairs).squeeze(-1)
         y = torch.cat([torch.ones(len(pos[0]), device=g.device), torch.zeros(len(neg[0]), device=g.device)])
         if neg_valid is None:
             loss_bce = self.recon_loss(y_pred, y)
