@@ -317,25 +317,56 @@ def graph(data, num_nodes: Optional[int] = None) -> Graph:
     return Graph(src, dst, num_nodes)
 
 
-def _cat_plans(plans, ptr, n_off, e_off) -> SegmentPlan:
+class _Offsets:
+    """Per-element offset vectors of a union of components (few launches instead of one add per
+    component and array).  ``vec(offsets, counts)`` = offsets[i] repeated counts[i] times."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self._memo = {}
+
+    def _small(self, values, dtype):
+        t = torch.tensor(values, dtype=dtype, pin_memory=self.dev.type == "cuda")
+        return t.to(self.dev, non_blocking=True)   # pinned + asynchronous: no host wait for the stream
+
+    def vec(self, offsets, counts, dtype=torch.int32) -> torch.Tensor:
+        key = (tuple(offsets), tuple(counts), dtype)
+        if key not in self._memo:
+            total = int(sum(counts))
+            self._memo[key] = torch.repeat_interleave(self._small(list(offsets), dtype),
+                                                      self._small(list(counts), torch.int64), output_size=total)
+        return self._memo[key]
+
+
+def _cat_plans(plans, ptr, n_off, e_off, offs: _Offsets) -> SegmentPlan:
     """Plan of a union graph from the plans of its components: heavy nodes and their chunks keep
     their order, ids and edge positions shift by the component offsets.  Equal to
     ``build_segment_plan(ptr)`` element for element, without its size-dependent host round trips."""
     dev = ptr.device
+    nh = [p.n_heavy for p in plans]
+    nc = [p.n_chunks for p in plans]
     h_off, c_off = [0], [0]
     for p in plans:
         h_off.append(h_off[-1] + p.n_heavy)
         c_off.append(c_off[-1] + p.n_chunks)
     i32 = torch.int32
-    heavy_node = torch.cat([p.heavy_node + n_off[i] for i, p in enumerate(plans)]).to(i32)
-    heavy_cptr = torch.cat([p.heavy_cptr[:-1] + c_off[i] for i, p in enumerate(plans)] +
-                           [torch.full((1,), c_off[-1], dtype=i32, device=dev)]).to(i32)
-    chunk_node = torch.cat([p.chunk_node + h_off[i] for i, p in enumerate(plans)]).to(i32)
-    chunk_beg = torch.cat([p.chunk_beg + e_off[i] for i, p in enumerate(plans)]).to(i32)
-    chunk_end = torch.cat([p.chunk_end + e_off[i] for i, p in enumerate(plans)]).to(i32)
+
+    def cat(attr, cut_last=False):
+        return torch.cat([getattr(p, attr)[:-1] if cut_last else getattr(p, attr) for p in plans])
+    if h_off[-1]:
+        heavy_node = cat("heavy_node") + offs.vec(n_off[:-1], nh)
+        heavy_cptr = torch.cat([cat("heavy_cptr", True) + offs.vec(c_off[:-1], nh),
+                                torch.full((1,), c_off[-1], dtype=i32, device=dev)])
+        chunk_node = cat("chunk_node") + offs.vec(h_off[:-1], nc)
+        e_vec = offs.vec(e_off[:-1], nc)
+        chunk_beg, chunk_end = cat("chunk_beg") + e_vec, cat("chunk_end") + e_vec
+    else:
+        heavy_node = chunk_node = chunk_beg = chunk_end = torch.zeros(0, dtype=i32, device=dev)
+        heavy_cptr = torch.zeros(1, dtype=i32, device=dev)
     deg = (ptr[1:] - ptr[:-1]).to(torch.int64)
     order = torch.sort(walk_class(deg), stable=True).indices.to(i32)
-    return SegmentPlan(ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end, order=order)
+    return SegmentPlan(ptr, heavy_node.to(i32), heavy_cptr.to(i32), chunk_node.to(i32), chunk_beg.to(i32),
+                       chunk_end.to(i32), order=order)
 
 
 def batch(graphs: Sequence[Graph]) -> Graph:
@@ -349,28 +380,35 @@ def batch(graphs: Sequence[Graph]) -> Graph:
     graphs = list(graphs)
     assert len(graphs) > 0
     dev = graphs[0].device
+    n_cnt = [g.num_nodes() for g in graphs]
+    e_cnt = [g.num_edges() for g in graphs]
     n_off, e_off = [0], [0]
     for g in graphs:
         n_off.append(n_off[-1] + g.num_nodes())
         e_off.append(e_off[-1] + g.num_edges())
-    src = torch.cat([g._s.src + n_off[i] for i, g in enumerate(graphs)])
-    dst = torch.cat([g._s.dst + n_off[i] for i, g in enumerate(graphs)])
+    offs = _Offsets(dev)
+
+    def cat(attr):
+        return torch.cat([getattr(g._s, attr) for g in graphs])
+    node_off_per_edge64 = offs.vec(n_off[:-1], e_cnt, torch.int64)
+    src = cat("src") + node_off_per_edge64
+    dst = cat("dst") + node_off_per_edge64
     s = Structure(src, dst, n_off[-1])
     if all(g._s.has_csr() for g in graphs):
         # no device synchronisation below: every size is already known on the host
-        def cat_ptr(attr):
-            parts = [getattr(graphs[0]._s, attr)]
-            for i, g in enumerate(graphs[1:], 1):
-                parts.append(getattr(g._s, attr)[1:] + e_off[i])
-            return torch.cat(parts).to(torch.int32)
+        i32 = torch.int32
+        node_off_per_edge = offs.vec(n_off[:-1], e_cnt)
+        edge_off_per_edge = offs.vec(e_off[:-1], e_cnt)
+        edge_off_per_node = offs.vec(e_off[:-1], n_cnt)
+        zero = torch.zeros(1, dtype=i32, device=dev)
 
-        def cat_off(attr, offs):
-            return torch.cat([getattr(g._s, attr) + offs[i] for i, g in enumerate(graphs)]).to(torch.int32)
-        s.in_ptr, s.in_src, s.in_eid = cat_ptr("in_ptr"), cat_off("in_src", n_off), cat_off("in_eid", e_off)
-        s.out_ptr, s.out_dst, s.out_eid = cat_ptr("out_ptr"), cat_off("out_dst", n_off), cat_off("out_eid", e_off)
-        s.in_dst, s.out_pos = cat_off("in_dst", n_off), cat_off("out_pos", e_off)
-        s.plan_in = _cat_plans([g._s.plan_in for g in graphs], s.in_ptr, n_off, e_off)
-        s.plan_out = _cat_plans([g._s.plan_out for g in graphs], s.out_ptr, n_off, e_off)
+        def cat_ptr(attr):
+            return torch.cat([zero, torch.cat([getattr(g._s, attr)[1:] for g in graphs]) + edge_off_per_node]).to(i32)
+        s.in_ptr, s.out_ptr = cat_ptr("in_ptr"), cat_ptr("out_ptr")
+        s.in_src, s.out_dst, s.in_dst = (cat(a) + node_off_per_edge for a in ("in_src", "out_dst", "in_dst"))
+        s.in_eid, s.out_eid, s.out_pos = (cat(a) + edge_off_per_edge for a in ("in_eid", "out_eid", "out_pos"))
+        s.plan_in = _cat_plans([g._s.plan_in for g in graphs], s.in_ptr, n_off, e_off, offs)
+        s.plan_out = _cat_plans([g._s.plan_out for g in graphs], s.out_ptr, n_off, e_off, offs)
     out = Graph(None, _structure=s)
     for k in graphs[0].ndata:
         if all(k in g.ndata for g in graphs):
