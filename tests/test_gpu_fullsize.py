@@ -137,3 +137,68 @@ def test_knn_properties_full_size(cuda):
         parts.append((dd, ii))
     md, mi = merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     assert torch.equal(mi, idx) and torch.equal(md, dist)
+
+
+def test_streamspot_batch_step_reproducible_and_directional_derivative(cuda):
+    """The benchmark's default workload (a batch of 12 StreamSpot-sized graphs, hidden 256, 4 layers:
+    the wide-layer kernels): union CSR equal to a direct sort, bitwise reproducible step, and the
+    loss changing along the gradient as the gradient says."""
+    import magic_amd
+    from magic_amd.graph import Structure
+    from magic_amd.model.autoencoder import GMAEModel
+    n1, e1, n_dim, e_dim, hidden, layers = synth.SHAPES["streamspot"]
+    parts = [synth.make_graph(n1, e1, n_dim, e_dim, seed=1002 + i, attrs=False).to(cuda) for i in range(12)]
+    for p in parts:
+        p.structure.ensure_csr()
+    g = magic_amd.batch(parts)
+    n, e = g.num_nodes(), g.num_edges()
+    assert (n, e) == (12 * n1, sum(p.num_edges() for p in parts))
+    direct = Structure(g.edges()[0], g.edges()[1], n).ensure_csr()
+    for name in ("in_ptr", "in_src", "in_eid", "out_ptr", "out_dst", "out_eid", "out_pos"):
+        assert torch.equal(getattr(g.structure, name), getattr(direct, name)), name
+    g.edata["attr"] = torch.nn.functional.one_hot(g.edata["type"], e_dim).float()
+    torch.manual_seed(0)
+    model = GMAEModel(n_dim, e_dim, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(cuda)
+    with torch.no_grad():
+        model.enc_mask_token.normal_(0, 0.3)
+    model.train()
+    gen = torch.Generator().manual_seed(3)
+    perm = torch.randperm(n, generator=gen).to(cuda)
+    pos = torch.randint(0, e, (10000,), generator=gen)
+    neg = (torch.randint(0, n, (10000,), generator=gen), torch.randint(0, n, (10000,), generator=gen))
+    widths = [n_dim] + [hidden] * (layers - 1) + [hidden]
+    masks = [(torch.rand(n, w, device=cuda) < 0.9) for w in widths]
+
+    def run():
+        g.ndata["attr"] = torch.nn.functional.one_hot(g.ndata["type"], n_dim).float()
+        model.zero_grad(set_to_none=True)
+        loss = model.compute_loss(g, perm=perm, pos_idx=pos, neg_pairs=neg, drop_masks=masks)
+        loss.backward()
+        return loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    l1, g1 = run()
+    l2, g2 = run()
+    assert torch.equal(l1, l2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+        assert bool(torch.isfinite(g1[k]).all()), k
+    names = ["encoder.gats.2.fc.weight", "encoder.gats.0.attn_h", "decoder.gats.0.fc.weight",
+             "encoder_to_decoder.weight", "edge_recon_fc.0.weight"]
+    params = dict(model.named_parameters())
+    # central difference along each tensor's own gradient direction, step sized for a predicted loss
+    # change of 0.01 per side (large enough against the ~1e-5 noise of an fp32 loss of O(1), small
+    # enough for the third-order term)
+    for k in names:
+        norm = float((g1[k].double() ** 2).sum()) ** 0.5
+        eps = 0.01 / norm
+
+        def shift(scale):
+            with torch.no_grad():
+                params[k].add_(g1[k] * (scale * eps / norm))
+        shift(1)
+        lp = float(run()[0])
+        shift(-2)
+        lm = float(run()[0])
+        shift(1)
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - norm) / norm < 0.05, (k, fd, norm)
