@@ -49,6 +49,52 @@ __global__ __launch_bounds__(256) void k_scatter_add(int n, int width, const int
     dst[(int64_t)r * ld_dst + c] = acc;
 }
 
+// float4 form: one wave per position, the whole row width in passes of up to four 256-column slabs
+// (lane l owns columns [4l, 4l+4) of every slab; the loads of a pass are issued together).
+// Needs width % 4 == 0 and 16-byte aligned rows on both sides.
+__global__ __launch_bounds__(256) void k_scatter_add4(int n, int width, const int32_t *key, const int32_t *pos,
+                                                      const float *src, int64_t ld_src, float *dst, int64_t ld_dst) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int r = key[i];
+    if (i > 0 && key[i - 1] == r) return;  // not the head of its run
+    int end = i + 1;
+    for (;;) {
+        const int j = end + lane;
+        const unsigned long long same = __ballot(j < n && key[j] == r);
+        if (same == ~0ull) {
+            end += 64;
+            continue;
+        }
+        end += __ffsll((long long)~same) - 1;
+        break;
+    }
+    float *drow = dst + (int64_t)r * ld_dst;
+    for (int c0 = lane * 4; c0 < width; c0 += 1024) {
+        float4 acc[4];
+        bool on[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            on[q] = c0 + 256 * q < width;
+            if (on[q]) acc[q] = *reinterpret_cast<const float4 *>(drow + c0 + 256 * q);
+        }
+        for (int j = i; j < end; ++j) {
+            const float *srow = src + (int64_t)pos[j] * ld_src + c0;
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (on[q]) v[q] = *reinterpret_cast<const float4 *>(srow + 256 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (on[q]) acc[q].x += v[q].x, acc[q].y += v[q].y, acc[q].z += v[q].z, acc[q].w += v[q].w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (on[q]) *reinterpret_cast<float4 *>(drow + c0 + 256 * q) = acc[q];
+    }
+}
+
 int bits_for(int64_t n) {
     int b = 1;
     while (b < 31 && ((int64_t)1 << b) < n) ++b;
@@ -94,8 +140,15 @@ int magic_rows_scatter_add(int64_t n_src, int64_t n_rows, int32_t width, const i
                                                stream) != hipSuccess)
             return MAGIC_ERR_RUNTIME;
     }
-    MAGIC_LAUNCH("rows_scatter_add", k_scatter_add, dim3((unsigned)n_src, (unsigned)((width + 255) / 256)), 256, 0, stream, (int)n_src, width, key_s, pos_s, src,
-                 ld_src, dst, ld_dst);
+    // (narrow rows leave most of a wave idle in the float4 form: measured 74 us against 47 us at width 192)
+    const bool vec = width >= 512 && (width % 4 == 0) && (ld_src % 4 == 0) && (ld_dst % 4 == 0) && ((uintptr_t)src % 16 == 0) &&
+                     ((uintptr_t)dst % 16 == 0);
+    if (vec)
+        MAGIC_LAUNCH("rows_scatter_add", k_scatter_add4, (unsigned)((n_src + 3) / 4), 256, 0, stream, (int)n_src, width,
+                     key_s, pos_s, src, ld_src, dst, ld_dst);
+    else
+        MAGIC_LAUNCH("rows_scatter_add", k_scatter_add, dim3((unsigned)n_src, (unsigned)((width + 255) / 256)), 256, 0,
+                     stream, (int)n_src, width, key_s, pos_s, src, ld_src, dst, ld_dst);
     return magic::launch_status();
 }
 
