@@ -6,7 +6,7 @@ parameter names, construction order (so seeds and state dicts carry over) and
 is re-expressed for the MI355X:
 
 * node phase -- ``fc`` (``:284``), the per-head scores ``eh``/``et`` (``:291-292``) and the
-  residual projection ``res_fc`` (``:323``) are one fp32 MFMA GEMM against an augmented
+  residual projection ``res_fc`` (``:323``) are one matrix-core GEMM (fp32-grade split-bf16 products) against an augmented
   weight ``W_aug = [W_fc ; fold(W_fc, attn_h) ; fold(W_fc, attn_t) ; W_res]`` where
   ``fold(W, a)[h, :] = sum_d a[h, d] * W[h*D + d, :]`` (``eh = (h W^T) . attn_h`` is linear
   in ``h``, so it is a GEMM column).  ``_FoldFn`` builds ``W_aug`` in one launch and maps the
@@ -129,7 +129,7 @@ class _GATLayerFn(torch.autograd.Function):
 
 
 class _LinearNoBiasFn(torch.autograd.Function):
-    """y = x W^T on the fp32 MFMA kernels (forward, input and weight gradients)."""
+    """y = x W^T on the projection kernels of this library (forward, input and weight gradients)."""
 
     @staticmethod
     def forward(ctx, x, w):
