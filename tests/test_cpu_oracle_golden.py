@@ -335,3 +335,60 @@ def test_sample_range_equals_random_sample():
         assert [random.random(), random.getrandbits(64)] == after
     with pytest.raises(ValueError):
         sample_range(5, 6)
+
+
+def test_node_link_reader_equals_networkx_route():
+    """graph_from_node_link against the route the reference takes (utils/loaddata.py:62-66):
+    nx.node_link_graph, then DGL's relabelling (convert_node_labels_to_integers, ordering='sorted')
+    and its edge / attribute order (iteration order of the relabelled DiGraph)."""
+    nx = pytest.importorskip("networkx")
+    import json
+    import warnings
+    from magic_amd.utils.loaddata import graph_from_node_link
+    rng = np.random.default_rng(3)
+    for trial in range(4):
+        n = 40 + 10 * trial
+        labels = rng.permutation(np.arange(100, 100 + 3 * n, 3))[:n].tolist()      # shuffled, gapped ids
+        nodes = [{"type": int(rng.integers(0, 8)), "id": int(lab)} for lab in labels]
+        links = []
+        for _ in range(6 * n):
+            u, v = (int(x) for x in rng.choice(labels[: n - 3], 2))                # three nodes stay isolated
+            links.append({"type": int(rng.integers(0, 20)), "source": u, "target": v})
+        links += [{"type": int(rng.integers(0, 20)), "source": e["source"], "target": e["target"]}
+                  for e in links[:15]]                                             # repeated pairs, new attributes
+        data = {"directed": True, "multigraph": False, "graph": {}, "nodes": nodes, "links": links}
+        data = json.loads(json.dumps(data))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                gx = nx.node_link_graph(data, edges="links")
+            except TypeError:
+                gx = nx.node_link_graph(data)
+        hx = nx.convert_node_labels_to_integers(gx, ordering="sorted")
+        want_edges = [(u, v, d["type"]) for u, v, d in hx.edges(data=True)]
+        want_ntype = [hx.nodes[i]["type"] for i in range(hx.number_of_nodes())]
+        g = graph_from_node_link(data)
+        src, dst = g.edges()
+        got_edges = list(zip(src.tolist(), dst.tolist(), g.edata["type"].tolist()))
+        assert g.num_nodes() == hx.number_of_nodes()
+        assert got_edges == want_edges
+        assert g.ndata["type"].tolist() == want_ntype
+
+
+def test_json_dataset_files_and_labels(tmp_path):
+    """Wget layout of utils/loaddata.py:133-150: <root>/wget/final/{0..149}.json, graphs 0-24 attacks."""
+    import json
+    from magic_amd.utils.loaddata import load_batch_level_dataset, load_json_dataset
+    d = tmp_path / "wget" / "final"
+    d.mkdir(parents=True)
+    for i in range(150):
+        data = {"directed": True, "multigraph": False, "graph": {},
+                "nodes": [{"type": (i + j) % 5, "id": j} for j in range(4)],
+                "links": [{"type": (i + j) % 3, "source": j, "target": (j + 1) % 4} for j in range(4)]}
+        (d / f"{i}.json").write_text(json.dumps(data))
+    ds = load_json_dataset("wget", root=str(tmp_path))
+    assert len(ds) == 150 and [y for _, y in ds] == [1] * 25 + [0] * 125
+    info = load_batch_level_dataset("wget")
+    assert info["n_feat"] == 5 and info["e_feat"] == 3 and info["train_index"] == list(range(25, 150))
+    g = ds[7][0]
+    assert g.num_nodes() == 4 and g.edges()[0].tolist() == [0, 1, 2, 3] and g.edges()[1].tolist() == [1, 2, 3, 0]

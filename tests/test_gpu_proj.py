@@ -106,6 +106,7 @@ def test_proj_bwd_input_against_float64(cuda, n, k, f, full):
 @pytest.mark.parametrize("n,m_,f,mask", [
     (5000, 72, 64, True), (5000, 64, 192, False), (3001, 18, 64, True), (2000, 136, 5, True),
     (1500, 264, 256, True), (999, 136, 10, False), (40, 72, 64, False),
+    (1500, 256, 1024, False), (901, 256, 384, True), (77, 128, 128, True),   # block-tiled kernel of the wide layers
 ])
 def test_proj_bwd_weight_against_float64(cuda, n, m_, f, mask):
     gen = torch.Generator(device=cuda).manual_seed(n + m_ + f)
