@@ -34,7 +34,8 @@ typedef enum magic_status {
     MAGIC_ERR_UNSUPPORTED = -2,   /* head count / head width without a compiled kernel */
     MAGIC_ERR_WORKSPACE = -3,     /* workspace missing or too small */
     MAGIC_ERR_LAUNCH = -4,        /* hipGetLastError() reported a launch failure */
-    MAGIC_ERR_RUNTIME = -5        /* another HIP runtime call failed */
+    MAGIC_ERR_RUNTIME = -5,       /* another HIP runtime call failed */
+    MAGIC_ERR_STATIC_LIMIT = -6   /* input larger than the static scratch of a no-allocation entry point */
 } magic_status;
 
 /* Library ABI version (bumped on any signature change). */
@@ -269,6 +270,22 @@ int magic_sce_fwd_bwd(int64_t n_rows, int32_t n_dim, int64_t n_mask, const int64
                       float alpha, float grad_scale,
                       float *loss, float *d_x, float *d_target_row,
                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* magic_sce_fwd_bwd without a workspace argument and without any allocation.  Has no
+ * counterpart in the reference; it is for callers that cannot allocate device memory or hand
+ * over a workspace: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  The per-block partial sums live in a static device array of the library
+ * (1024 x (1 + 16) floats = 69,632 bytes per GPU, held until the process ends), so n_dim is
+ * limited to MAGIC_SCE_STATIC_MAX_DIM; a wider row returns MAGIC_ERR_STATIC_LIMIT (use
+ * magic_sce_fwd_bwd).  Same arguments, results bit-identical to magic_sce_fwd_bwd.  The call
+ * runs no hipMalloc / hipFree / event creation; the first call on a GPU resolves that GPU's
+ * copy of the array (hipGetSymbolAddress) with the caller's device current.  All calls on one
+ * GPU share the array: calls that overlap on one GPU (two streams, two threads) race. */
+#define MAGIC_SCE_STATIC_MAX_DIM 16
+int magic_sce_fwd_bwd_static(int64_t n_rows, int32_t n_dim, int64_t n_mask, const int64_t *mask_idx,
+                             const float *x, int64_t ld_x, const float *target, int64_t ld_t,
+                             float alpha, float grad_scale,
+                             float *loss, float *d_x, float *d_target_row, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Brute-force k nearest neighbours (Euclidean), replacing

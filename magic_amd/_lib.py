@@ -59,6 +59,8 @@ SYMBOLS = {
     "magic_sce_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "magic_sce_fwd_bwd": (c_i32, [c_i64, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32,
                                   c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "magic_sce_fwd_bwd_static": (c_i32, [c_i64, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32,
+                                         c_vp, c_vp, c_vp, c_vp]),
     "magic_knn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32]),
     "magic_knn_topk": (c_i32, [c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp,
                                c_vp, c_sz, c_vp]),

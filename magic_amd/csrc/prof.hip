@@ -58,7 +58,7 @@ void prof_end(hipStream_t s) {
 
 extern "C" {
 
-int magic_abi_version(void) { return 1; }
+int magic_abi_version(void) { return 2; }
 
 const char *magic_status_string(int status) {
     switch (status) {
@@ -68,6 +68,7 @@ const char *magic_status_string(int status) {
         case MAGIC_ERR_WORKSPACE: return "workspace missing or too small";
         case MAGIC_ERR_LAUNCH: return "kernel launch failed";
         case MAGIC_ERR_RUNTIME: return "HIP runtime call failed";
+        case MAGIC_ERR_STATIC_LIMIT: return "input exceeds the static scratch of the no-allocation entry point";
         default: return "unknown status";
     }
 }

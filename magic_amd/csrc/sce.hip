@@ -4,6 +4,7 @@
 // gradient of a shared single-row target.
 #include "common.h"
 #include <math.h>
+#include <mutex>
 
 namespace {
 
@@ -116,6 +117,41 @@ __global__ __launch_bounds__(256) void k_sce_final(SceArgs a) {
 
 int sce_grid(int64_t n_mask) { return magic::stride_grid(n_mask, 256, 1024); }
 
+int sce_check(int64_t n_rows, int32_t n_dim, int64_t n_mask, const int64_t *mask_idx, const float *x, int64_t ld_x,
+              const float *target, int64_t ld_t, const float *loss, const float *d_x, const float *d_target_row) {
+    if (n_rows < 0 || n_mask <= 0 || n_dim <= 0 || n_dim > kMaxDim) return n_dim > kMaxDim ? MAGIC_ERR_UNSUPPORTED : MAGIC_ERR_INVALID_ARG;
+    if (!mask_idx || !x || !target || !loss || !d_x || ld_x < n_dim || (ld_t != 0 && ld_t < n_dim)) return MAGIC_ERR_INVALID_ARG;
+    if (d_target_row && ld_t != 0) return MAGIC_ERR_INVALID_ARG;
+    return MAGIC_OK;
+}
+
+// ---- scratch of the entry point that allocates nothing -------------------------------------------
+// Per-block partial sums of the loss ([kStaticGrid]) and of the single-row target gradient
+// ([kStaticGrid, kStaticMaxDim]).  One copy per GPU, held until the process ends.  Host code never
+// uses the array's name as an address: the per-device address comes from hipGetSymbolAddress.
+constexpr int kStaticGrid = 1024;    // = the grid cap of sce_grid()
+constexpr int kStaticMaxDim = 16;    // widest feature row served (MAGIC's datasets have n_dim 5..13)
+constexpr size_t kScratchFloats = (size_t)kStaticGrid * (1 + kStaticMaxDim);
+static __device__ __align__(256) float scratch[kScratchFloats];
+
+constexpr int kMaxDevices = 64;
+float *g_scratch_ptr[kMaxDevices];   // device address of `scratch` on each GPU, resolved on first use
+std::mutex g_scratch_mu;
+
+// Address of this GPU's copy of `scratch` (resolved once per device, with that device current).
+int scratch_for_current_device(float **out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return MAGIC_ERR_RUNTIME;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return MAGIC_ERR_RUNTIME;
+        g_scratch_ptr[dev] = (float *)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return MAGIC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -128,9 +164,8 @@ size_t magic_sce_workspace_bytes(int64_t n_mask, int32_t n_dim) {
 int magic_sce_fwd_bwd(int64_t n_rows, int32_t n_dim, int64_t n_mask, const int64_t *mask_idx, const float *x,
                       int64_t ld_x, const float *target, int64_t ld_t, float alpha, float grad_scale, float *loss,
                       float *d_x, float *d_target_row, void *workspace, size_t workspace_bytes, void *stream_) {
-    if (n_rows < 0 || n_mask <= 0 || n_dim <= 0 || n_dim > kMaxDim) return n_dim > kMaxDim ? MAGIC_ERR_UNSUPPORTED : MAGIC_ERR_INVALID_ARG;
-    if (!mask_idx || !x || !target || !loss || !d_x || ld_x < n_dim || (ld_t != 0 && ld_t < n_dim)) return MAGIC_ERR_INVALID_ARG;
-    if (d_target_row && ld_t != 0) return MAGIC_ERR_INVALID_ARG;
+    const int st = sce_check(n_rows, n_dim, n_mask, mask_idx, x, ld_x, target, ld_t, loss, d_x, d_target_row);
+    if (st != MAGIC_OK) return st;
     hipStream_t stream = (hipStream_t)stream_;
     SceArgs a;
     a.n_mask = n_mask;
@@ -153,6 +188,40 @@ int magic_sce_fwd_bwd(int64_t n_rows, int32_t n_dim, int64_t n_mask, const int64
     if (hipMemsetAsync(d_x, 0, sizeof(float) * (size_t)n_rows * ld_x, stream) != hipSuccess) return MAGIC_ERR_RUNTIME;
     MAGIC_LAUNCH("sce_fwd_bwd", k_sce, a.grid, 256, 0, stream, a);
     MAGIC_LAUNCH("sce_final", k_sce_final, 1, 256, 0, stream, a);
+    return magic::launch_status();
+}
+
+int magic_sce_fwd_bwd_static(int64_t n_rows, int32_t n_dim, int64_t n_mask, const int64_t *mask_idx, const float *x,
+                             int64_t ld_x, const float *target, int64_t ld_t, float alpha, float grad_scale,
+                             float *loss, float *d_x, float *d_target_row, void *stream_) {
+    const int st = sce_check(n_rows, n_dim, n_mask, mask_idx, x, ld_x, target, ld_t, loss, d_x, d_target_row);
+    if (st != MAGIC_OK) return st;
+    if (n_dim > kStaticMaxDim) return MAGIC_ERR_STATIC_LIMIT;
+    hipStream_t stream = (hipStream_t)stream_;
+    SceArgs a;
+    a.n_mask = n_mask;
+    a.n_dim = n_dim;
+    a.mask = mask_idx;
+    a.x = x;
+    a.ld_x = ld_x;
+    a.t = target;
+    a.ld_t = ld_t;
+    a.alpha = alpha;
+    a.grad_scale = grad_scale;
+    a.d_x = d_x;
+    a.grid = sce_grid(n_mask);
+    a.loss = loss;
+    a.d_trow = d_target_row;
+    if (a.grid > kStaticGrid) return MAGIC_ERR_STATIC_LIMIT;
+    float *base = nullptr;
+    const int sp = scratch_for_current_device(&base);
+    if (sp != MAGIC_OK) return sp;
+    a.ws_loss = base;                 // [grid]          every entry is rewritten by its block below:
+    a.ws_dt = base + kStaticGrid;     // [grid, n_dim]   nothing has to start at zero
+    if (hipMemsetAsync(d_x, 0, sizeof(float) * (size_t)n_rows * ld_x, stream) != hipSuccess) return MAGIC_ERR_RUNTIME;
+    // plain launches: the timing brackets of MAGIC_LAUNCH create events
+    hipLaunchKernelGGL(k_sce, dim3(a.grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_sce_final, dim3(1), dim3(256), 0, stream, a);
     return magic::launch_status();
 }
 
