@@ -13,6 +13,7 @@ namespace magic {
 bool prof_on();
 void prof_begin(const char *name, hipStream_t s);
 void prof_end(hipStream_t s);
+const char *prof_name(const char *base, int a, int b);  // "base<a,b>", static storage
 
 struct ProfScope {
     hipStream_t s;

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void k_bwd_table_final(BwdArgs a, int H) {
     if (threadIdx.x == 0) a.d_table[o] = red[0];
 }
 
-template <int H>
+template <int H, int LPH>
 int launch_table(BwdArgs &a, hipStream_t stream) {
     if (!a.etype || !a.d_table) return MAGIC_OK;
     if (a.E == 0) {
@@ -522,7 +522,7 @@ int launch_table(BwdArgs &a, hipStream_t stream) {
             return MAGIC_ERR_RUNTIME;
         attr_bytes = sh;
     }
-    MAGIC_LAUNCH("gat_bwd_table_partial", (k_bwd_table_partial<H>), a.grid_table, TBL_THREADS, sh, stream, a);
+    MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_table_partial", H, LPH) : "gat_bwd_table_partial", (k_bwd_table_partial<H>), a.grid_table, TBL_THREADS, sh, stream, a);
     MAGIC_LAUNCH("gat_bwd_table_final", k_bwd_table_final, a.e_dim * H, 256, 0, stream, a, H);
     return MAGIC_OK;
 }
@@ -532,30 +532,30 @@ int launch_bwd(BwdArgs &a, hipStream_t stream) {
     constexpr int C = H * LPH * 4;
     constexpr int NPB = 256 / (H * LPH);
     if (a.prelu_w || a.d_bias || a.d_pre != a.d_out) {
-        MAGIC_LAUNCH("gat_bwd_node_adjoint", (k_bwd_node_adjoint<H, LPH>), a.grid_light, 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_node_adjoint", H, LPH) : "gat_bwd_node_adjoint", (k_bwd_node_adjoint<H, LPH>), a.grid_light, 256, 0, stream, a);
         if (a.d_bias || a.d_prelu)
             MAGIC_LAUNCH("gat_bwd_reduce_bias", k_bwd_reduce_bias, C + 1, 256, 0, stream, a, C);
     }
-    MAGIC_LAUNCH("gat_bwd_src_light", (k_bwd_src_light<H, LPH>), stride_grid(a.N, NPB, 256 * 16), 256, 0, stream, a);
+    MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_light<H, LPH>), stride_grid(a.N, NPB, 256 * 16), 256, 0, stream, a);
     if (a.pout.n_chunks > 0) {
         const int cgrid = (a.pout.n_chunks + 3) / 4;
-        MAGIC_LAUNCH("gat_bwd_src_heavy1", (k_bwd_src_heavy1<H, LPH>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_heavy1", H, LPH) : "gat_bwd_src_heavy1", (k_bwd_src_heavy1<H, LPH>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_bwd_src_heavy2", (k_bwd_src_heavy2<H, LPH>), a.pout.n_heavy, 256, 0, stream, a);
     }
     const int ngrid = stride_grid(a.N, 256, 256 * 16);
-    MAGIC_LAUNCH("gat_bwd_dst_light", (k_bwd_dst_light<H>), ngrid, 256, 0, stream, a, C);
+    MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_dst_light", H, LPH) : "gat_bwd_dst_light", (k_bwd_dst_light<H>), ngrid, 256, 0, stream, a, C);
     if (a.pin.n_chunks > 0) {
         const int cgrid = (a.pin.n_chunks + 3) / 4;
         MAGIC_LAUNCH("gat_bwd_dst_heavy1", (k_bwd_dst_heavy1<H>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_bwd_dst_heavy2", (k_bwd_dst_heavy2<H>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_bwd_dst_heavy3", (k_bwd_dst_heavy3<H>), (a.pin.n_heavy + 3) / 4, 256, 0, stream, a, C);
     }
-    MAGIC_LAUNCH("gat_bwd_deh_light", (k_bwd_deh_light<H>), ngrid, 256, 0, stream, a, C);
+    MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_deh_light", H, LPH) : "gat_bwd_deh_light", (k_bwd_deh_light<H>), ngrid, 256, 0, stream, a, C);
     if (a.pout.n_chunks > 0) {
         MAGIC_LAUNCH("gat_bwd_deh_heavy1", (k_bwd_deh_heavy1<H>), (a.pout.n_chunks + 3) / 4, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_bwd_deh_heavy2", (k_bwd_deh_heavy2<H>), (a.pout.n_heavy + 3) / 4, 256, 0, stream, a, C);
     }
-    int st = launch_table<H>(a, stream);
+    int st = launch_table<H, LPH>(a, stream);
     if (st != MAGIC_OK) return st;
     return launch_status();
 }

@@ -317,18 +317,18 @@ int launch_fwd(const FwdArgs &a, bool table, hipStream_t stream) {
     if (a.E > 0) {
         int grid = stride_grid(a.E, 256, 256 * 32);
         if (table)
-            MAGIC_LAUNCH("gat_edge_logits", (k_edge_logits<H, true>), grid, 256, 0, stream, a);
+            MAGIC_LAUNCH(prof_on() ? prof_name("gat_edge_logits", H, LPH) : "gat_edge_logits", (k_edge_logits<H, true>), grid, 256, 0, stream, a);
         else
-            MAGIC_LAUNCH("gat_edge_logits", (k_edge_logits<H, false>), grid, 256, 0, stream, a);
+            MAGIC_LAUNCH(prof_on() ? prof_name("gat_edge_logits", H, LPH) : "gat_edge_logits", (k_edge_logits<H, false>), grid, 256, 0, stream, a);
     }
     if (a.N > 0) {
         int grid = stride_grid(a.N, NPB, 256 * 32);
-        MAGIC_LAUNCH("gat_fwd_light", (k_fwd_light<H, LPH>), grid, 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_light", H, LPH) : "gat_fwd_light", (k_fwd_light<H, LPH>), grid, 256, 0, stream, a);
     }
     if (a.plan.n_chunks > 0) {
         int cgrid = (a.plan.n_chunks + 3) / 4;
         MAGIC_LAUNCH("gat_fwd_heavy_stats", (k_fwd_heavy_stats<H>), cgrid, 256, 0, stream, a);
-        MAGIC_LAUNCH("gat_fwd_heavy_agg", (k_fwd_heavy_agg<H, LPH>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_heavy_agg", H, LPH) : "gat_fwd_heavy_agg", (k_fwd_heavy_agg<H, LPH>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_fwd_heavy_finish", (k_fwd_heavy_finish<H, LPH>), a.plan.n_heavy, 256, 0, stream, a);
     }
     return launch_status();

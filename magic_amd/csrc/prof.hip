@@ -34,6 +34,18 @@ hipEvent_t get_event() {
 
 bool prof_on() { return g_on; }
 
+// "<base><a,b>" with static storage (one string per distinct combination), so that the template
+// instances of one kernel are timed apart
+const char *prof_name(const char *base, int a, int b) {
+    static std::map<std::string, std::string> names;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    std::string key = std::string(base) + "<" + std::to_string(a) + "," + std::to_string(b) + ">";
+    auto it = names.find(key);
+    if (it == names.end()) it = names.emplace(key, key).first;
+    return it->second.c_str();
+}
+
 void prof_begin(const char *name, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_open_a = get_event();

@@ -201,3 +201,25 @@ def test_embedding_extraction_round_robin_world2(tmp_path):
     for a, b, n in zip(r0["outs"], r1["outs"], (5, 9, 1, 12, 7)):
         want = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3) * (n + 1)
         assert torch.equal(a, want) and torch.equal(b, want)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` without a launcher must start two ranks itself (before touching a
+    GPU) and report n_gpus = 2; --dry-run keeps the launch plumbing and drops the GPU work."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3"],
+                         capture_output=True, text=True, timeout=180, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                      # one JSON line, from rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["dry_run"] is True
+    # a launcher that gives a different world size is refused instead of mislabelled
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                         capture_output=True, text=True, timeout=60, env=env2, cwd=root)
+    assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build profiles/traffic.json and profiles/r01_pmc_summary_<workload>.txt from two rocprofv3 --pmc
+"""Build profiles/traffic.json and profiles/<round>_pmc_summary_<workload>.txt from two rocprofv3 --pmc
 passes (FETCH_SIZE in one run, WRITE_SIZE in another) over `bench.py --steps 2 --warmup 1`.
 
 HBM bytes per launch = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB.  The factor 2 on the read side is the
@@ -17,7 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarise  # noqa: E402
 
 BENCH_NAME = {"k_fwd_light": "gat_fwd_light", "k_bwd_src_light": "gat_bwd_src_light",
-              "k_bwd_dst_light": "gat_bwd_dst_light", "k_edge_logits": "gat_edge_logits"}
+              "k_bwd_dst_light": "gat_bwd_dst_light", "k_bwd_deh_light": "gat_bwd_deh_light",
+              "k_edge_logits": "gat_edge_logits"}
+ROUND = os.environ.get("MAGIC_PROFILE_ROUND", "r02")
 
 
 def main():
@@ -48,14 +50,20 @@ def main():
         total = (2 * f + w) * 1024
         lines.append(f"{k:44s} {f:12.0f} {w:12.0f} {total / 1e6:16.1f}")
         traffic[k] = total
-    # bench.py reports per name over all layers: launch-weighted mean of the template instances
-    # (the encoder layers <4,LPH> and one decoder layer <1,LPH> per step)
+    # bench.py reports one row per template instance ("gat_bwd_src_light<4,4>")
     out = {}
-    for prefix, name in BENCH_NAME.items():
-        enc = [v for k, v in traffic.items() if k.startswith(prefix + "<4")]
-        dec = [v for k, v in traffic.items() if k.startswith(prefix + "<1")]
-        if enc and dec:
-            out[name] = int((n_enc * enc[0] + dec[0]) / (n_enc + 1))
+    lph_of = {}     # head count -> lanes per head of this workload's layers (from the two-argument templates)
+    for k in traffic:
+        args = k.split("<", 1)[1].rstrip(">").replace(" ", "").split(",") if "<" in k else []
+        if k.startswith("k_bwd_src_light<") and len(args) == 2:
+            lph_of[args[0]] = args[1]
+    for k, v in traffic.items():
+        base = k.split("<")[0]
+        if base in BENCH_NAME and "<" in k:
+            args = k.split("<", 1)[1].rstrip(">").replace(" ", "").split(",")
+            if len(args) == 1 or base == "k_edge_logits":      # templated on the head count only
+                args = [args[0], lph_of.get(args[0], "?")]
+            out[BENCH_NAME[base] + "<" + ",".join(args) + ">"] = int(v)
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
     path = os.path.join(root, "traffic.json")
     data = {}
@@ -63,7 +71,7 @@ def main():
         data = json.load(open(path))
     data[workload] = out
     json.dump(data, open(path, "w"), indent=1, sort_keys=True)
-    open(os.path.join(root, f"r01_pmc_summary_{workload}.txt"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(root, f"{ROUND}_pmc_summary_{workload}.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:3]))
     print(out)
 
