@@ -288,6 +288,20 @@ int magic_sce_fwd_bwd_static(int64_t n_rows, int32_t n_dim, int64_t n_mask, cons
                              float *loss, float *d_x, float *d_target_row, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Graph read-out (utils/poolers.py:49-73, called from model/eval.py:59-68): mean (mean != 0) or
+ * sum of the node embeddings feat [N,width].  n_types == 0: over all nodes, out [width]
+ * (:50-53).  n_types > 0: per node type t in [0, n_types) (node_type [N] int64, the reference's
+ * graph.ndata['type']; ids outside that range belong to no type), the per-type rows
+ * concatenated, out [n_types * width], zeros for a type without nodes (:59-72; Unicorn-Wget:
+ * 8 types x 256).  The reference's 'max' read-out returns a (values, indices) tuple and is not
+ * provided.  One pass over feat, fixed summation order, no host synchronisation.  n_types <= 32.
+ * ---------------------------------------------------------------------------------- */
+size_t magic_readout_workspace_bytes(int64_t n_rows, int32_t width, int32_t n_types);
+int magic_readout(int64_t n_rows, int32_t width, const float *feat, int64_t ld_feat,
+                  const int64_t *node_type, int32_t n_types, int32_t mean, float *out /* [max(n_types,1)*width] */,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Brute-force k nearest neighbours (Euclidean), replacing
  * sklearn.neighbors.NearestNeighbors(...).kneighbors at model/eval.py:154,158 and
  * :306,311.  Squared distances |q|^2 - 2 q.t + |t|^2 are formed in float64 on the f64

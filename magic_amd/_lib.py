@@ -61,6 +61,8 @@ SYMBOLS = {
                                   c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_sce_fwd_bwd_static": (c_i32, [c_i64, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32,
                                          c_vp, c_vp, c_vp, c_vp]),
+    "magic_readout_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
+    "magic_readout": (c_i32, [c_i64, c_i32, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "magic_knn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32]),
     "magic_knn_topk": (c_i32, [c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp,
                                c_vp, c_sz, c_vp]),
@@ -429,6 +431,25 @@ def sce_fwd_bwd(x: torch.Tensor, n_dim: int, target: torch.Tensor, single_row: b
                                  _dev(target, torch.float32, "target"), ld_t, float(alpha), 1.0, _dev(loss),
                                  _dev(d_x), _dev(d_t), ws.data_ptr(), ws.numel(), _stream()), "magic_sce_fwd_bwd")
     return loss, d_x[:, :x.shape[1]], d_t
+
+
+# ------------------------------------------------------------------------------------- read-out
+def readout(feat: torch.Tensor, node_type: Optional[torch.Tensor], n_types: int, mean: bool) -> torch.Tensor:
+    """[1, max(n_types, 1) * width] mean / sum read-out of feat [N, width] (per node type when n_types > 0)."""
+    lib = load()
+    assert feat.dim() == 2
+    feat = _rows(feat)
+    N, W = feat.shape
+    dev = feat.device
+    if n_types:
+        node_type = node_type.view(-1).to(device=dev, dtype=torch.int64).contiguous()
+        assert node_type.numel() == N
+    out = torch.empty(1, max(n_types, 1) * W, dtype=torch.float32, device=dev)
+    ws = workspace(lib.magic_readout_workspace_bytes(N, W, n_types), dev)
+    _check(lib.magic_readout(N, W, _dev(feat, torch.float32, "feat"), feat.stride(0),
+                             _dev(node_type) if n_types else None, int(n_types), 1 if mean else 0, _dev(out),
+                             ws.data_ptr(), ws.numel(), _stream()), "magic_readout")
+    return out
 
 
 # ------------------------------------------------------------------------------------- KNN

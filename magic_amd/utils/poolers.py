@@ -1,37 +1,31 @@
-"""Graph read-out (``utils/poolers.py``): mean / sum / max over nodes, optionally per node type."""
-import torch
+"""Graph read-out with the reference's interface (``utils/poolers.py``), on the MI355X.
+
+``Pooling(pooler)(graph, feat, n_types=None)``: mean or sum of the node embeddings, over all
+nodes (``[1, hidden]``) or, with ``n_types``, per value of ``graph.ndata['type']`` with the per-type
+rows side by side (``[1, n_types * hidden]``, zeros for a type without nodes) -- what
+``model/eval.py:64-68`` feeds the batch-level detector (Unicorn-Wget: 8 x 256).  One segmented pass
+over the embeddings (``magic_readout``): no Python loop over the types and no host round trip per
+type.
+"""
 import torch.nn as nn
+
+from .. import _lib
 
 
 class Pooling(nn.Module):
     def __init__(self, pooler):
         super().__init__()
+        if pooler not in ("mean", "sum", "max"):
+            raise NotImplementedError(pooler)
         self.pooler = pooler
 
     def forward(self, graph, feat, n_types=None):
-        """``utils/poolers.py:48-73``.  With ``n_types`` the result is the concatenation of the
-        per-type read-outs ``[1, n_types * hidden]`` (zeros for an absent type)."""
-        with graph.local_scope():
-            if not n_types:
-                if self.pooler == "mean":
-                    return feat.mean(0, keepdim=True)
-                if self.pooler == "sum":
-                    return feat.sum(0, keepdim=True)
-                if self.pooler == "max":
-                    return feat.max(0, keepdim=True)
-                raise NotImplementedError
-            result = []
-            types = graph.ndata["type"]
-            for i in range(n_types):
-                mask = (types == i)
-                if not mask.any():
-                    result.append(torch.zeros((1, feat.shape[-1]), device=feat.device))
-                elif self.pooler == "mean":
-                    result.append(feat[mask].mean(0, keepdim=True))
-                elif self.pooler == "sum":
-                    result.append(feat[mask].sum(0, keepdim=True))
-                elif self.pooler == "max":
-                    result.append(feat[mask].max(0, keepdim=True))
-                else:
-                    raise NotImplementedError
-            return torch.cat(result, dim=-1)
+        if self.pooler == "max":
+            # utils/poolers.py:54-55,69 returns torch's (values, indices) pair there, which none of its
+            # callers can use; no kernel is provided for it
+            raise NotImplementedError("'max' read-out: the reference returns a (values, indices) tuple "
+                                      "its callers cannot consume; use 'mean' or 'sum'")
+        if feat.device.type != "cuda":
+            raise _lib.MagicHipError("magic_amd.Pooling runs on the MI355X only (no CPU fallback)")
+        types = graph.ndata["type"] if n_types else None
+        return _lib.readout(feat, types, int(n_types or 0), self.pooler == "mean")

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import rel_err, small_graph, to_graph, to_ograph
+from tests.util import rel_err, row_rel_err, small_graph, to_graph, to_ograph
 from oracle import gat_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -120,6 +120,8 @@ def _model_pair(n_dim, e_dim, hidden, layers, dev, seed=0, alias=True):
     ((12, 9, 128, 2), False, "drop"),
     ((5, 17, 64, 3), True, "negslope"),      # PReLU slopes <= 0: pre-activation must come from storage
     ((6, 7, 32, 2), True, "drop"),
+    ((8, 4, 256, 4), True, "drop"),          # Unicorn-Wget dims (train.py:53-56)
+    ((8, 4, 256, 4), False, "eval"),
     ((5, 17, 64, 3), True, "tiny"),          # 33 nodes / 70 edges: ragged last row tile everywhere
 ])
 def test_autoencoder_loss_and_grads(cuda, shape, alias, mode):
@@ -163,7 +165,9 @@ def test_autoencoder_loss_and_grads(cuda, shape, alias, mode):
     assert abs(float(parts_m["sce"]) - float(parts_o["sce"])) / abs(float(parts_o["sce"])) < 1e-4
     for hm, ho in zip(parts_m["hidden"], parts_o["hidden"]):
         assert rel_err(hm, ho) < 1e-4
+        assert row_rel_err(hm, ho) < 1e-4          # every node's embedding row, relative to itself
     assert rel_err(parts_m["recon"], parts_o["recon"]) < 1e-4
+    assert row_rel_err(parts_m["recon"], parts_o["recon"]) < 1e-4
     lo.backward()
     lm.backward()
     for (k, po), (_, pm) in zip(ref64.named_parameters(), mine.named_parameters()):
@@ -216,6 +220,7 @@ def test_embed_matches_oracle_and_is_deterministic(cuda):
         e1 = mine.embed(g)
         e2 = mine.embed(g)
     assert rel_err(e1, eo) < 1e-4
+    assert row_rel_err(e1, eo) < 1e-4   # per node, relative to that node's own embedding
     assert torch.equal(e1, e2)   # no atomics anywhere: bitwise reproducible
 
 

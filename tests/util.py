@@ -55,3 +55,17 @@ def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def row_rel_err(a, b, floor=1e-3):
+    """Per-row relative error: max over rows of ||a_row - b_row|| / ||b_row||, taken over the rows
+    whose reference norm is at least ``floor`` times the largest row norm (rows that are numerically
+    zero have no meaningful relative error).  Stricter than ``rel_err``, which normalises by the
+    largest entry of the whole tensor."""
+    a = a.detach().double().cpu().reshape(a.shape[0], -1)
+    b = b.detach().double().cpu().reshape(b.shape[0], -1)
+    nb = b.norm(dim=1)
+    keep = nb >= floor * float(nb.max() + 1e-300)
+    if not bool(keep.any()):
+        return 0.0
+    return float(((a - b).norm(dim=1)[keep] / nb[keep]).max())
