@@ -198,6 +198,9 @@ int magic_rows_scatter_add(int64_t n_src, int64_t n_rows, int32_t width, const i
  * tensor itself is never written.
  * ---------------------------------------------------------------------------------- */
 int magic_dropout_mask(int64_t n_elems, float keep_prob, uint64_t seed, uint8_t *mask, void *stream);
+/* Same mask, the seed read from device memory when the kernel runs (seed_dev[0]): a launch recorded
+ * in a HIP graph draws a new mask at every replay after the caller rewrote that word. */
+int magic_dropout_mask_dev(int64_t n_elems, float keep_prob, const uint64_t *seed_dev, uint8_t *mask, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Operands of magic_proj_fwd / magic_gat_fwd built from the layer's parameters in one launch

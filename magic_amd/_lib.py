@@ -46,6 +46,7 @@ SYMBOLS = {
     "magic_rows_scatter_add_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "magic_rows_scatter_add": (c_i32, [c_i64, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "magic_dropout_mask": (c_i32, [c_i64, c_f32, C.c_uint64, c_vp, c_vp]),
+    "magic_dropout_mask_dev": (c_i32, [c_i64, c_f32, c_vp, c_vp, c_vp]),
     "magic_fold_fwd": (c_i32, [c_i32] * 5 + [c_vp] * 10 + [c_vp]),
     "magic_fold_bwd": (c_i32, [c_i32] * 5 + [c_vp] * 15 + [c_vp]),
     "magic_gat_fwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
@@ -307,6 +308,17 @@ def dropout_mask(shape, keep_prob: float, seed: int, device) -> torch.Tensor:
     m = torch.empty(shape, dtype=torch.uint8, device=device)
     _check(lib.magic_dropout_mask(m.numel(), float(keep_prob), int(seed) & 0xFFFFFFFFFFFFFFFF, _dev(m), _stream()),
            "magic_dropout_mask")
+    return m
+
+
+def dropout_mask_dev(shape, keep_prob: float, seed_dev: torch.Tensor, device) -> torch.Tensor:
+    """Same as :func:`dropout_mask` with the seed taken from ``seed_dev[0]`` (int64, on the GPU) when the
+    kernel runs, so the launch can be recorded in a HIP graph."""
+    lib = load()
+    assert seed_dev.dtype == torch.int64 and seed_dev.numel() >= 1
+    m = torch.empty(shape, dtype=torch.uint8, device=device)
+    _check(lib.magic_dropout_mask_dev(m.numel(), float(keep_prob), _dev(seed_dev), _dev(m), _stream()),
+           "magic_dropout_mask_dev")
     return m
 
 

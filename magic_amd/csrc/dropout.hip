@@ -28,7 +28,11 @@ __device__ __forceinline__ void philox10(uint64_t seed, uint64_t ctr, uint32_t (
 }
 
 // every thread fills 16 consecutive bytes: two Philox blocks, 16 random bits per element
-__global__ __launch_bounds__(256) void k_dropout_mask(int64_t n, uint32_t thr16, uint64_t seed, uint8_t *out) {
+// (the seed comes by value, or from device memory when `seed_dev` is given: a launch recorded in a
+// HIP graph then draws a fresh mask at every replay once the caller has rewritten that word)
+__global__ __launch_bounds__(256) void k_dropout_mask(int64_t n, uint32_t thr16, uint64_t seed, const uint64_t *seed_dev,
+                                                      uint8_t *out) {
+    if (seed_dev) seed = seed_dev[0];
     const int64_t n16 = (n + 15) / 16;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
         uint32_t r[8];
@@ -58,7 +62,8 @@ __global__ __launch_bounds__(256) void k_dropout_mask(int64_t n, uint32_t thr16,
 
 extern "C" {
 
-int magic_dropout_mask(int64_t n_elems, float keep_prob, uint64_t seed, uint8_t *mask, void *stream_) {
+static int dropout_launch(int64_t n_elems, float keep_prob, uint64_t seed, const uint64_t *seed_dev, uint8_t *mask,
+                          void *stream_) {
     if (n_elems < 0 || !(keep_prob >= 0.f && keep_prob <= 1.f)) return MAGIC_ERR_INVALID_ARG;
     if (n_elems == 0) return MAGIC_OK;
     if (!mask || ((uintptr_t)mask & 15)) return MAGIC_ERR_INVALID_ARG;
@@ -66,8 +71,17 @@ int magic_dropout_mask(int64_t n_elems, float keep_prob, uint64_t seed, uint8_t 
     uint32_t thr = (uint32_t)(keep_prob * 65536.f + 0.5f);
     if (thr > 65536u) thr = 65536u;
     MAGIC_LAUNCH("dropout_mask", k_dropout_mask, magic::stride_grid((n_elems + 15) / 16, 256, 4096), 256, 0,
-                 (hipStream_t)stream_, n_elems, thr, seed, mask);
+                 (hipStream_t)stream_, n_elems, thr, seed, seed_dev, mask);
     return magic::launch_status();
+}
+
+int magic_dropout_mask(int64_t n_elems, float keep_prob, uint64_t seed, uint8_t *mask, void *stream) {
+    return dropout_launch(n_elems, keep_prob, seed, nullptr, mask, stream);
+}
+
+int magic_dropout_mask_dev(int64_t n_elems, float keep_prob, const uint64_t *seed_dev, uint8_t *mask, void *stream) {
+    if (!seed_dev) return MAGIC_ERR_INVALID_ARG;
+    return dropout_launch(n_elems, keep_prob, 0, seed_dev, mask, stream);
 }
 
 }  // extern "C"

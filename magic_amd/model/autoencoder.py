@@ -37,6 +37,16 @@ def build_model(args):
         mask_rate=args.mask_rate, norm="BatchNorm", loss_fn="sce", alpha_l=args.alpha_l)
 
 
+def _sorted_edge_keys(g: Graph) -> torch.Tensor:
+    """src * N + dst of every edge, ascending (cached on the structure: a graph's edges never change)."""
+    s = g.structure
+    keys = getattr(s, "_edge_keys", None)
+    if keys is None:
+        src, dst = g.edges()
+        keys = s._edge_keys = torch.sort(src * g.num_nodes() + dst).values
+    return keys
+
+
 def _negative_candidates(g: Graph, num_samples: int, generator: torch.Generator = None):
     """``num_samples`` uniformly drawn (src, dst) pairs and the mask of those that are neither edges
     of ``g`` nor self-loops (fixed shapes: nothing is read back to the host)."""
@@ -44,8 +54,7 @@ def _negative_candidates(g: Graph, num_samples: int, generator: torch.Generator 
     dev = g.device
     u = torch.randint(0, n, (num_samples,), device=dev, generator=generator)
     v = torch.randint(0, n, (num_samples,), device=dev, generator=generator)
-    src, dst = g.edges()
-    ekey = torch.sort(src * n + dst).values
+    ekey = _sorted_edge_keys(g)
     key = u * n + v
     pos = torch.searchsorted(ekey, key).clamp_(max=max(ekey.numel() - 1, 0))
     is_edge = (ekey[pos] == key) if ekey.numel() else torch.zeros_like(key, dtype=torch.bool)
@@ -168,21 +177,27 @@ class GMAEModel(nn.Module):
     def forward(self, g, **overrides):
         return self.compute_loss(g, **overrides)
 
-    def _dropout_masks(self, widths, n, device, drop_masks):
+    def _dropout_masks(self, widths, n, device, drop_masks, drop_seeds=None):
         """One uint8 keep mask per GAT layer input (``model/gat.py:283``), or Nones when dropout
-        is inactive.  ``drop_masks`` (0/1 tensors, any dtype) replaces the Bernoulli draws."""
+        is inactive.  ``drop_masks`` (0/1 tensors, any dtype) replaces the Bernoulli draws;
+        ``drop_seeds`` (int64 tensor on the GPU, one word per mask) replaces the seeds drawn from
+        torch's CPU generator and is read when the kernels run (HIP-graph replays draw new masks)."""
         p = self.encoder.gats[0].feat_drop.p
         if drop_masks is not None:
             assert len(drop_masks) == len(widths)
             return [m.to(device=device, dtype=torch.uint8).contiguous() for m in drop_masks], 1.0 / (1.0 - p)
         if not self.training or p == 0.0:
             return [None] * len(widths), 1.0
+        if drop_seeds is not None:
+            assert drop_seeds.numel() >= len(widths) and drop_seeds.dtype == torch.int64
+            return [_lib.dropout_mask_dev((n, w), 1.0 - p, drop_seeds[i:i + 1], device)
+                    for i, w in enumerate(widths)], 1.0 / (1.0 - p)
         # one 63-bit seed per mask from torch's CPU generator (reproducible under torch.manual_seed,
         # no device synchronisation); the masks themselves are drawn on the GPU
         seeds = torch.randint(0, 2 ** 62, (len(widths),)).tolist()
         return [_lib.dropout_mask((n, w), 1.0 - p, s, device) for w, s in zip(widths, seeds)], 1.0 / (1.0 - p)
 
-    def _fused_cfg(self, g: Graph, drop_masks):
+    def _fused_cfg(self, g: Graph, drop_masks, drop_seeds=None):
         """Description of the whole encoder -> decoder chain for ``FusedGMAEFn``, or None when a
         layer needs the generic per-layer path (norm layers, non-PReLU activations, head widths
         that need padding inside the encoder, dense edge attributes ...)."""
@@ -210,7 +225,7 @@ class GMAEModel(nn.Module):
             return None
         n = g.num_nodes()
         widths = [enc[0].src_feat] + [H * D] * (len(enc) - 1) + [d.src_feat]
-        masks, scale = self._dropout_masks(widths, n, g.device, drop_masks)
+        masks, scale = self._dropout_masks(widths, n, g.device, drop_masks, drop_seeds)
         return FusedCfg(g.structure.ensure_csr(), etype, enc[0].edge_feat, len(enc), H, D, d.out_feat,
                         _pad_head_dim(d.out_feat), enc[0].leaky_relu.negative_slope, res_kinds, masks, scale)
 
@@ -224,8 +239,10 @@ class GMAEModel(nn.Module):
         return sig(_LinearFn.apply(h, fc2.weight, fc2.bias))
 
     def compute_loss(self, g: Graph, perm=None, pos_idx=None, neg_pairs=None, drop_masks=None, return_parts=False,
-                     fused=True):
-        """``model/autoencoder.py:218-267``.  ``fused=False`` forces the layer-by-layer path."""
+                     fused=True, neg_valid=None, drop_seeds=None):
+        """``model/autoencoder.py:218-267``.  ``fused=False`` forces the layer-by-layer path.
+        ``neg_valid`` (bool mask) marks which of the injected ``neg_pairs`` count (the rest get weight 0
+        in the BCE, as the candidates this method draws itself); ``drop_seeds``: see ``_dropout_masks``."""
         feat_has_grad = g.ndata["attr"].requires_grad
         pre_use_g, (mask_nodes, keep_nodes) = self.encoding_mask_noise(g, self._mask_rate, perm)
         pre_use_x = pre_use_g.ndata["attr"].to(pre_use_g.device)
@@ -233,7 +250,6 @@ class GMAEModel(nn.Module):
         # autoencoder.py:248-256: node pairs of the sampled edge reconstruction (drawn first: the
         # fused chain gathers their hidden rows itself)
         threshold = min(10000, g.num_nodes())
-        neg_valid = None
         if neg_pairs is None:
             # all k candidates go through the head, the rejected ones with weight 0 in the loss: the
             # same mean over the accepted pairs as selecting them first, without a host round trip
@@ -253,7 +269,7 @@ class GMAEModel(nn.Module):
         n_pairs = len(pos[0]) + len(neg[0])
         sample_idx = torch.cat([pos[0], neg[0], pos[1], neg[1]])
 
-        cfg = self._fused_cfg(use_g, drop_masks) if fused else None
+        cfg = self._fused_cfg(use_g, drop_masks, drop_seeds) if fused else None
         if cfg is not None:
             params = []
             for layer in self.encoder.gats:

@@ -15,7 +15,12 @@ def create_optimizer(opt, model, lr, weight_decay):
     parameters = model.parameters()
     opt_args = dict(lr=lr, weight_decay=weight_decay)
     if opt_lower == "adam":
-        return optim.Adam(parameters, **opt_args)
+        # one multi-tensor launch per step instead of a chain of element-wise launches per parameter
+        # (same update rule; the model lives on the GPU by the time the reference builds its
+        # optimizer: train.py:99-101)
+        params = list(parameters)
+        on_gpu = len(params) > 0 and all(p.device.type == "cuda" for p in params)
+        return optim.Adam(params, fused=on_gpu, **opt_args)
     if opt_lower == "adamw":
         return optim.AdamW(parameters, **opt_args)
     if opt_lower == "adadelta":
