@@ -311,7 +311,7 @@ class GMAEModel(nn.Module):
         if neg_valid is None:
             loss_bce = self.recon_loss(y_pred, y)
         else:
-            w = torch.cat([torch.ones(len(pos[0]), device=g.device), neg_valid.float()])
+            w = torch.cat([torch.ones(len(pos[0]), device=g.device), torch.as_tensor(neg_valid).to(g.device).float()])
             loss_bce = nn.functional.binary_cross_entropy(y_pred, y, weight=w, reduction="sum") / w.sum()
         loss = loss + loss_bce
         if return_parts:

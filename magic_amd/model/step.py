@@ -55,11 +55,18 @@ class CapturedTrainStep:
     reference's loaders rebuild them) and one-hot ``edata['attr']``.  ``loss_scale`` multiplies the loss
     before backward (``train.py:113``: ``loss /= n_train``).  ``grad_exchange`` (a
     :class:`magic_amd.parallel.FlatGradAllReduce`) runs between backward and the optimizer step; the
-    step is then recorded as two graphs around that collective.  ``optimizer`` must be capturable
-    (:func:`make_adam`)."""
+    step is then recorded as two graphs around that collective.
+
+    ``capture=False`` (the default) runs the same statements eagerly on the caller's stream.  Measured
+    on MI355X / ROCm 7.2 the replayed step is not faster than the eager one at any of the benchmark's
+    shapes (its ~180 launches keep the device busy back to back either way; what separates them is
+    the device-side kernel boundary, which a replay does not remove), so recording is an option for
+    callers whose host thread is busy elsewhere, not the default.  With ``capture=True`` the
+    ``optimizer`` must be capturable (:func:`make_adam`) and every step of the model runs on one side
+    stream, eager warm-up calls included."""
 
     def __init__(self, model, optimizer, g, n_dim: int, loss_scale: float = 1.0, grad_exchange=None,
-                 warmup: int = 2, capture: bool = True, capture_optimizer: bool = True):
+                 warmup: int = 2, capture: bool = False, capture_optimizer: bool = True):
         self.model, self.opt, self.g, self.n_dim = model, optimizer, g, n_dim
         self.loss_scale, self.exchange = float(loss_scale), grad_exchange
         dev = g.device
@@ -78,21 +85,23 @@ class CapturedTrainStep:
         self.neg_u = torch.zeros(self.thr, dtype=torch.int64, device=dev)   # candidate negative pairs
         self.neg_v = torch.zeros(self.thr, dtype=torch.int64, device=dev)
         self.neg_ok = torch.zeros(self.thr, dtype=torch.bool, device=dev)   # ... and which of them count
-        self._copied = None     # event behind the last host-to-device copies of the inputs
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self._graphs = None
         self._capture = capture
         self._capture_opt = capture_optimizer
         self._warmup = warmup
-        self._pin = {}
         self._calls = 0
 
     # ------------------------------------------------------------------ pieces of one step
-    def _forward_backward(self):
+    def _forward_backward(self, inputs=None):
+        """``inputs``: keyword overrides of ``compute_loss`` (eager mode), or None for the static
+        input buffers of the recorded step."""
         g, m = self.g, self.model
         g.ndata["attr"] = torch.nn.functional.one_hot(self.ntype, self.n_dim).float()
-        loss = m.compute_loss(g, perm=self.perm, pos_idx=self.pos, neg_pairs=(self.neg_u, self.neg_v),
-                              neg_valid=self.neg_ok, drop_seeds=self.seeds)
+        if inputs is None:
+            inputs = dict(perm=self.perm, pos_idx=self.pos, neg_pairs=(self.neg_u, self.neg_v),
+                          neg_valid=self.neg_ok, drop_seeds=self.seeds)
+        loss = m.compute_loss(g, **inputs)
         if self.loss_scale != 1.0:
             loss = loss * self.loss_scale
         if self.exchange is not None:
@@ -105,8 +114,8 @@ class CapturedTrainStep:
         # place): drop it now instead of keeping that graph alive until the next step
         g.ndata.pop("attr", None)
 
-    def _eager(self):
-        self._forward_backward()
+    def _eager(self, inputs=None):
+        self._forward_backward(inputs)
         if self.exchange is not None:
             self.exchange.allreduce()
         self.opt.step()
@@ -142,15 +151,13 @@ class CapturedTrainStep:
 
     # ------------------------------------------------------------------ per-step inputs
     def _load(self, name, dst, value):
-        """Copy a host tensor into a static device tensor through a reused pinned buffer."""
-        if value.device.type == "cuda":
-            dst.copy_(value)
-            return
-        pin = self._pin.get(name)
-        if pin is None or pin.shape != value.shape:
-            pin = self._pin[name] = torch.empty(value.shape, dtype=dst.dtype).pin_memory()
-        pin.copy_(value)
-        dst.copy_(pin, non_blocking=True)
+        """Copy a tensor into a static device tensor; host tensors go through pinned memory from
+        torch's caching host allocator (which does not recycle a block before its copy has run)."""
+        if value.device.type != "cuda":
+            pin = torch.empty(value.shape, dtype=dst.dtype, pin_memory=True)
+            pin.copy_(value)
+            value = pin
+        dst.copy_(value, non_blocking=True)
 
     def set_inputs(self, perm=None, pos_idx=None, seeds=None, neg_pairs=None, neg_valid=None):
         """Defaults follow the reference: ``torch.randperm`` from torch's CPU generator (the device
@@ -160,8 +167,6 @@ class CapturedTrainStep:
         generator.  ``neg_pairs`` must hold exactly T = min(10000, N) pairs."""
         from .autoencoder import _negative_candidates
         dev = self.g.device
-        if self._copied is not None:
-            self._copied.synchronize()      # the pinned staging buffers are reused: wait for their last copy
         if perm is None:
             perm = torch.randperm(self.n, device=dev) if self.model.mask_rng == "device" else torch.randperm(self.n)
         self._load("perm", self.perm, torch.as_tensor(perm).long())
@@ -179,9 +184,6 @@ class CapturedTrainStep:
         self.neg_u.copy_(u)
         self.neg_v.copy_(v)
         self.neg_ok.copy_(ok)
-        if self._copied is None:
-            self._copied = torch.cuda.Event()
-        self._copied.record()
 
     def __call__(self, **inputs) -> torch.Tensor:
         """Run exactly one training step; returns the (scaled) loss as a device scalar that the next
@@ -189,6 +191,17 @@ class CapturedTrainStep:
         the kernel workspaces and create the optimizer state); the next call records the step and
         every call from then on replays it."""
         self.model.train()
+        if not self._capture:
+            # plain eager step on the caller's stream: the inputs go to compute_loss as they are
+            # (missing ones are drawn there as the reference draws them)
+            kw = {k: v for k, v in inputs.items() if v is not None}
+            if "seeds" in kw:
+                kw["drop_seeds"] = torch.as_tensor(kw.pop("seeds")).long().to(self.g.device)
+            if "perm" in kw:
+                kw["perm"] = torch.as_tensor(kw["perm"]).to(self.g.device)
+            self._calls += 1
+            self._eager(kw)
+            return self.loss
         self.set_inputs(**inputs)
         cur, st = torch.cuda.current_stream(), _shared_stream(self.model)
         st.wait_stream(cur)                 # the inputs were written on the caller's stream
@@ -198,7 +211,7 @@ class CapturedTrainStep:
         return self.loss
 
     def _step(self):
-        if not self._capture or self._calls < self._warmup:
+        if self._calls < self._warmup:
             self._calls += 1
             self._eager()
             return

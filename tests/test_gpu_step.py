@@ -144,7 +144,7 @@ def test_recorded_step_equals_eager_step_bitwise(cuda, inject_neg):
     src, dst, nt, et = small_graph(n, e, N_DIM, E_DIM, seed=91, hub_deg=300, hub_out=150)
     ga = to_graph(src, dst, n, nt, et, N_DIM, E_DIM, cuda)
     gb = to_graph(src, dst, n, nt, et, N_DIM, E_DIM, cuda)
-    sa = CapturedTrainStep(a, make_adam(a, 1e-3, 5e-4), ga, N_DIM, loss_scale=0.25, capture=False)
+    sa = CapturedTrainStep(a, make_adam(a, 1e-3, 5e-4), ga, N_DIM, loss_scale=0.25)
     sb = CapturedTrainStep(b, make_adam(b, 1e-3, 5e-4), gb, N_DIM, loss_scale=0.25, capture=True, warmup=2)
     gen = torch.Generator().manual_seed(8)
     t = min(10000, n)
