@@ -5,6 +5,7 @@ Public surface mirrors the reference modules: ``magic_amd.model.gat`` (GAT, GATC
 (sce_loss), ``magic_amd.model.eval`` (KNN evaluators), ``magic_amd.utils.*`` and the
 DGL-subset graph container ``magic_amd.graph`` (``Graph``, ``graph``, ``batch``).
 """
+from . import ops  # noqa: F401  (registers torch.ops.magic.*)
 from .graph import Graph, batch, graph  # noqa: F401
 
 __version__ = "0.1.0"

@@ -146,8 +146,8 @@ class Structure:
         if self.src.device.type != "cuda":
             raise RuntimeError("magic_amd: CSC/CSR construction runs on the MI355X only; "
                                "move the graph with .to('cuda') first")
-        from . import _lib
-        self.set_csr(*_lib.csr_build(self.src, self.dst, self.num_nodes))
+        from . import ops  # noqa: F401  (registers torch.ops.magic.*)
+        self.set_csr(*torch.ops.magic.csr_build(self.src, self.dst, self.num_nodes))
         return self
 
     def to(self, device) -> "Structure":

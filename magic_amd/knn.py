@@ -17,7 +17,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops  # noqa: F401  (ops registers torch.ops.magic.*)
 
 
 def _as_device_f32(x, device) -> torch.Tensor:
@@ -47,7 +47,7 @@ class NearestNeighbors:
                              f"n_samples_fit = {self._train.shape[0]}")
         dists, idxs = [], []
         for s in range(0, x.shape[0], self.query_block):
-            d, i = _lib.knn_topk(self._train, x[s:s + self.query_block], k, index_offset)
+            d, i = torch.ops.magic.knn_topk(self._train, x[s:s + self.query_block].contiguous(), k, index_offset)
             dists.append(d)
             idxs.append(i)
         if len(dists) == 1:
@@ -66,7 +66,7 @@ class NearestNeighbors:
 def merge_topk(part_dist: torch.Tensor, part_idx: torch.Tensor):
     """[P,Q,k] per-shard results -> [Q,k] global k best, ordered by (distance, index)."""
     if part_dist.device.type == "cuda":
-        return _lib.knn_merge(part_dist, part_idx)
+        return torch.ops.magic.knn_merge(part_dist, part_idx)
     # host tensors (used by the gloo tests of the exchange logic): same order rule
     P, Q, k = part_dist.shape
     d = part_dist.permute(1, 0, 2).reshape(Q, P * k)

@@ -21,7 +21,7 @@ from itertools import chain
 import torch
 import torch.nn as nn
 
-from .. import _lib
+from .. import _lib, ops
 from ..graph import Graph
 from ..utils.utils import create_norm, sample_range
 from .fused import FusedCfg, FusedGMAEFn
@@ -98,7 +98,7 @@ class _PairLinearFn(torch.autograd.Function):
             torch.mm(g, w[:, :width], out=d_rows[:n])
             torch.mm(g, w[:, width:], out=d_rows[n:])
         if ctx.needs_input_grad[2]:
-            d_w = torch.cat([_lib.proj_bwd_weight(g, rows[:n]), _lib.proj_bwd_weight(g, rows[n:])], dim=1)
+            d_w = torch.cat([ops.proj_bwd_weight(g, rows[:n]), ops.proj_bwd_weight(g, rows[n:])], dim=1)
         if ctx.needs_input_grad[3]:
             d_b = g.sum(0)
         return d_rows, None, d_w, d_b

@@ -26,7 +26,7 @@ from typing import List, Optional
 
 import torch
 
-from .. import _lib
+from .. import _lib, ops
 
 
 class FusedCfg:
@@ -72,23 +72,23 @@ class FusedGMAEFn(torch.autograd.Function):
             w_aug, table, bias, prelu_w = params[4 * l:4 * l + 4]
             mask = cfg.masks[l]
             kind = cfg.res_kinds[l]
-            hs, score, res = _lib.proj_fwd(inp, w_aug, C, 2 * H, C if kind == "linear" else 0,
+            hs, score, res = ops.proj_fwd(inp, w_aug, C, 2 * H, C if kind == "linear" else 0,
                                            x_mask=mask, x_scale=cfg.scale)
             res_mask = None
             if kind == "identity":
                 res, res_mask = inp, mask
             out_l = enc[:, l * C:(l + 1) * C]
-            _, pre, attn = _lib.gat_fwd(s, H, D, hs, score[:, :H], score[:, H:], table.contiguous(), cfg.etype, None,
+            _, pre, attn = ops.gat_fwd(s, H, D, hs, score[:, :H], score[:, H:], table.contiguous(), cfg.etype, None,
                                         cfg.slope, bias, res, prelu_w, True, res_mask=res_mask,
                                         res_scale=cfg.scale, out=out_l)
             saved += [hs, attn, pre]
             inp = out_l
         w_e2d = params[4 * L]
         w_aug_d, table_d, bias_d = params[4 * L + 1:4 * L + 4]
-        rep = _lib.proj_fwd(enc, w_e2d, w_e2d.shape[0], 0, 0)[0]
+        rep = ops.proj_fwd(enc, w_e2d, w_e2d.shape[0], 0, 0)[0]
         mask_d = cfg.masks[L]
-        hs_d, score_d, _ = _lib.proj_fwd(rep, w_aug_d, cfg.Dp, 2, 0, x_mask=mask_d, x_scale=cfg.scale)
-        recon, _, attn_d = _lib.gat_fwd(s, 1, cfg.Dp, hs_d, score_d[:, :1], score_d[:, 1:], table_d.contiguous(),
+        hs_d, score_d, _ = ops.proj_fwd(rep, w_aug_d, cfg.Dp, 2, 0, x_mask=mask_d, x_scale=cfg.scale)
+        recon, _, attn_d = ops.gat_fwd(s, 1, cfg.Dp, hs_d, score_d[:, :1], score_d[:, 1:], table_d.contiguous(),
                                         cfg.etype, None, cfg.slope, bias_d, None, None, False)
         samples = enc[sample_idx]
         ctx.cfg = cfg
@@ -119,15 +119,15 @@ class FusedGMAEFn(torch.autograd.Function):
             d_recon = torch.zeros(N, Dp, dtype=torch.float32, device=dev)
         d_recon = d_recon.contiguous()
         d_y = _aligned_rows(N, Dp + 2, dev)
-        d_table, _, d_bias, _ = _lib.gat_bwd(s, 1, Dp, hs_d, attn_d, cfg.etype, cfg.e_dim, cfg.slope, None, None, None,
+        d_table, _, d_bias, _ = ops.gat_bwd(s, 1, Dp, hs_d, attn_d, cfg.etype, cfg.e_dim, cfg.slope, None, None, None,
                                              d_recon, d_recon, d_y, True)
-        grads[4 * L + 1] = _lib.proj_bwd_weight(d_y, rep, x_mask=mask_d, x_scale=cfg.scale)
+        grads[4 * L + 1] = ops.proj_bwd_weight(d_y, rep, x_mask=mask_d, x_scale=cfg.scale)
         grads[4 * L + 2] = d_table
         grads[4 * L + 3] = d_bias
-        d_rep = _lib.proj_bwd_input(d_y, w_aug_d, out_mask=mask_d, out_scale=cfg.scale)[0]
+        d_rep = ops.proj_bwd_input(d_y, w_aug_d, out_mask=mask_d, out_scale=cfg.scale)[0]
         # ---- encoder_to_decoder
-        grads[4 * L] = _lib.proj_bwd_weight(d_rep, enc)
-        d_enc = _lib.proj_bwd_input(d_rep, w_e2d)[0]                   # [N, L*C]
+        grads[4 * L] = ops.proj_bwd_weight(d_rep, enc)
+        d_enc = ops.proj_bwd_input(d_rep, w_e2d)[0]                   # [N, L*C]
         if d_samples is not None:
             # rows used by the edge-reconstruction head (stable sort + run heads: reproducible)
             _lib.rows_scatter_add(d_enc, sample_idx, d_samples)
@@ -149,17 +149,17 @@ class FusedGMAEFn(torch.autograd.Function):
                 # sweep applies the PReLU adjoint and sums the bias / slope gradients itself
                 d_y = _aligned_rows(N, w_aug.shape[0], dev)
                 d_pre = d_y[:, off:] if kind == "linear" else torch.empty(N, C, dtype=torch.float32, device=dev)
-                d_table, _, bias_grad, prelu_grad = _lib.gat_bwd(
+                d_table, _, bias_grad, prelu_grad = ops.gat_bwd(
                     s, H, D, hs, attn, cfg.etype, cfg.e_dim, cfg.slope, pre, enc[:, l * C:(l + 1) * C], prelu_w,
                     d_enc[:, l * C:(l + 1) * C], d_pre, d_y, True)
             else:
                 d_y = d_y_next if d_y_next is not None else _aligned_rows(N, w_aug.shape[0], dev)
-                d_table = _lib.gat_bwd(s, H, D, hs, attn, cfg.etype, cfg.e_dim, cfg.slope, None, None, None,
+                d_table = ops.gat_bwd(s, H, D, hs, attn, cfg.etype, cfg.e_dim, cfg.slope, None, None, None,
                                        d_pre, d_pre, d_y, False)[0]
             token_path = (l == 0 and cfg.token_rows is not None and ctx.needs_input_grad[3]
                           and not ctx.needs_input_grad[0] and kind != "identity")
             if not token_path:  # (the token path below produces this layer's weight gradient itself)
-                grads[4 * l] = _lib.proj_bwd_weight(d_y, inp, x_mask=mask, x_scale=cfg.scale)
+                grads[4 * l] = ops.proj_bwd_weight(d_y, inp, x_mask=mask, x_scale=cfg.scale)
             grads[4 * l + 1] = d_table
             grads[4 * l + 2] = bias_grad
             grads[4 * l + 3] = prelu_grad.view_as(prelu_w)
@@ -170,7 +170,7 @@ class FusedGMAEFn(torch.autograd.Function):
                 if cfg.res_kinds[l - 1] == "linear":  # lands in the residual columns of layer l-1's d_y
                     d_y_next = _aligned_rows(N, params[4 * (l - 1)].shape[0], dev)
                     target = d_y_next[:, off:]
-                d_pre, bias_grad, prelu_grad = _lib.proj_bwd_input(
+                d_pre, bias_grad, prelu_grad = ops.proj_bwd_input(
                     d_y, w_aug, add=add, out_mask=mask, out_scale=cfg.scale, add2=d_enc[:, (l - 1) * C:l * C],
                     act_out=inp, act_pre=saved[3 * (l - 1) + 2], prelu_w=params[4 * (l - 1) + 3],
                     want_col_sum=True, out=target)
@@ -185,11 +185,11 @@ class FusedGMAEFn(torch.autograd.Function):
                     ind.index_fill_(0, cfg.token_rows, 1.0)
                     x2 = torch.cat([inp, ind.expand(N, F0)], 1)
                     m2 = torch.cat([mask, mask], 1) if mask is not None else None
-                    dw2 = _lib.proj_bwd_weight(d_y, x2, x_mask=m2, x_scale=cfg.scale)
+                    dw2 = ops.proj_bwd_weight(d_y, x2, x_mask=m2, x_scale=cfg.scale)
                     grads[0] = dw2[:, :F0]
                     d_token = (dw2[:, F0:] * w_aug).sum(0, keepdim=True)
                 elif ctx.needs_input_grad[0] or want_token:
-                    d_x = _lib.proj_bwd_input(d_y, w_aug, add=add)[0]
+                    d_x = ops.proj_bwd_input(d_y, w_aug, add=add)[0]
                     if mask is not None:  # [N, n_dim] is narrow: not worth an epilogue variant
                         d_x = d_x * mask * cfg.scale
                     if want_token:

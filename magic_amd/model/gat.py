@@ -25,7 +25,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .. import _lib
+from .. import _lib, ops
 from ..graph import Graph
 from ..utils.utils import create_activation
 
@@ -79,7 +79,7 @@ class _GATLayerFn(torch.autograd.Function):
         H, Dp, C = cfg["H"], cfg["Dp"], cfg["C"]
         res_c = cfg["res_c"]
         h = h.contiguous() if h.stride(-1) != 1 else h
-        hs, score, res = _lib.proj_fwd(h, w_aug, C, 2 * H, res_c)
+        hs, score, res = ops.proj_fwd(h, w_aug, C, 2 * H, res_c)
         if cfg["res_identity"]:
             res = h
         etype = cfg["etype_csc"]
@@ -88,7 +88,7 @@ class _GATLayerFn(torch.autograd.Function):
         else:
             table, ee_csc = None, edge_term[struct.in_eid.long()].contiguous()
         want_pre = prelu_w is not None and cfg["need_grad"]
-        out, pre, attn = _lib.gat_fwd(struct, H, Dp, hs, score[:, :H], score[:, H:], table, etype, ee_csc,
+        out, pre, attn = ops.gat_fwd(struct, H, Dp, hs, score[:, :H], score[:, H:], table, etype, ee_csc,
                                       cfg["slope"], bias, res, prelu_w, want_pre)
         ctx.struct, ctx.cfg = struct, cfg
         ctx.save_for_backward(h, w_aug, hs, attn, pre, prelu_w, out if prelu_w is not None else None)
@@ -109,16 +109,16 @@ class _GATLayerFn(torch.autograd.Function):
         else:
             d_pre = torch.empty(N, C, dtype=torch.float32, device=h.device)
         etype = cfg["etype_csc"]
-        d_table, rec, d_bias, d_prelu = _lib.gat_bwd(
+        d_table, rec, d_bias, d_prelu = ops.gat_bwd(
             struct, H, Dp, hs, attn, etype, cfg["e_dim"], cfg["slope"], pre, act_out, prelu_w, d_out, d_pre, d_y,
             cfg["has_bias"])
         if res_c and d_pre.data_ptr() != d_y[:, C + 2 * H:].data_ptr():
             d_y[:, C + 2 * H:] = d_pre
         d_h = d_w = d_edge = None
         if ctx.needs_input_grad[0]:
-            d_h = _lib.proj_bwd_input(d_y, w_aug, add=d_pre if cfg["res_identity"] else None)[0]
+            d_h = ops.proj_bwd_input(d_y, w_aug, add=d_pre if cfg["res_identity"] else None)[0]
         if ctx.needs_input_grad[1]:
-            d_w = _lib.proj_bwd_weight(d_y, h)
+            d_w = ops.proj_bwd_weight(d_y, h)
         if ctx.needs_input_grad[2]:
             if etype is not None:
                 d_edge = d_table
@@ -133,15 +133,15 @@ class _LinearNoBiasFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w):
-        y, _, _ = _lib.proj_fwd(x, w, w.shape[0], 0, 0)
+        y, _, _ = ops.proj_fwd(x, w, w.shape[0], 0, 0)
         ctx.save_for_backward(x, w)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dx = _lib.proj_bwd_input(dy, w)[0] if ctx.needs_input_grad[0] else None
-        dw = _lib.proj_bwd_weight(dy, x) if ctx.needs_input_grad[1] else None
+        dx = ops.proj_bwd_input(dy, w)[0] if ctx.needs_input_grad[0] else None
+        dw = ops.proj_bwd_weight(dy, x) if ctx.needs_input_grad[1] else None
         return dx, dw
 
 
@@ -159,7 +159,7 @@ class _LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dy @ w if ctx.needs_input_grad[0] else None
-        dw = _lib.proj_bwd_weight(dy, x) if ctx.needs_input_grad[1] else None
+        dw = ops.proj_bwd_weight(dy, x) if ctx.needs_input_grad[1] else None
         db = dy.sum(0) if ctx.needs_input_grad[2] else None
         return dx, dw, db
 

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch
 
-from .. import _lib
+from .. import _lib, ops
 
 
 class _SCEMaskedFn(torch.autograd.Function):
@@ -18,7 +18,7 @@ class _SCEMaskedFn(torch.autograd.Function):
             x = x.contiguous()
         if not single and target.stride(-1) != 1:
             target = target.contiguous()
-        loss, d_x, d_t = _lib.sce_fwd_bwd(x, n_dim, target, single, mask_idx, alpha)
+        loss, d_x, d_t = ops.sce_fwd_bwd(x, n_dim, target, single, mask_idx, alpha)
         ctx.single = single
         ctx.save_for_backward(d_x, d_t)
         ctx.t_shape = target.shape

@@ -1,0 +1,298 @@
+"""``torch.ops.magic.*``: the C ABI of ``libmagic_hip.so`` registered as PyTorch custom operators.
+
+Every operator has a schema, a CUDA (= ROCm) implementation that forwards raw device pointers to the
+library through ``magic_amd._lib``, and a fake (meta) implementation that only computes output
+shapes, so the operators can be traced / shape-checked without a GPU.  There is no CPU
+implementation: calling one with CPU tensors raises PyTorch's own "no kernel for backend CPU" error.
+Operators whose results land in caller-provided buffers carry a trailing underscore and declare those
+arguments as mutated (``Tensor(a!)``).  Absent optional outputs come back as empty tensors.
+
+Differentiable entry points built on them live next to the reference-shaped modules
+(``model/gat.py``, ``model/fused.py``, ``model/loss_func.py``); two operators also carry a registered
+autograd formula so that they can be used on their own: ``magic::sce_loss`` and
+``magic::linear_nobias``.
+
+The segment plan of a graph direction (``graph.SegmentPlan``) travels as seven int32 tensors:
+``ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end, order``.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+_L = torch.library.Library("magic", "DEF")
+_PLAN = "Tensor {0}ptr, Tensor {0}heavy_node, Tensor {0}heavy_cptr, Tensor {0}chunk_node, Tensor {0}chunk_beg, " \
+        "Tensor {0}chunk_end, Tensor {0}order"
+
+
+def _register(name: str, schema: str, impl, fake):
+    _L.define(f"{name}{schema}")
+    _L.impl(name, impl, "CUDA")
+    torch.library.register_fake(f"magic::{name}", fake)
+
+
+def _none(t: Optional[Tensor]) -> Optional[Tensor]:
+    return None if t is None or t.numel() == 0 else t
+
+
+def _empty(like: Tensor, dtype=torch.float32) -> Tensor:
+    return torch.empty(0, dtype=dtype, device=like.device)
+
+
+def _plan(ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end, order):
+    from .graph import SegmentPlan
+    return SegmentPlan(ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end,
+                       order=order if order.numel() else None)
+
+
+def plan_tensors(plan) -> List[Tensor]:
+    """The seven tensors of a ``graph.SegmentPlan`` in operator-argument order."""
+    order = plan.order if plan.order is not None else torch.empty(0, dtype=torch.int32, device=plan.ptr.device)
+    return [plan.ptr, plan.heavy_node, plan.heavy_cptr, plan.chunk_node, plan.chunk_beg, plan.chunk_end, order]
+
+
+# ------------------------------------------------------------------------------------- csr_build
+def _csr_build(src: Tensor, dst: Tensor, num_nodes: int):
+    return _lib.csr_build(src, dst, num_nodes)
+
+
+def _csr_build_fake(src, dst, num_nodes):
+    e = src.shape[0]
+    i32 = dict(dtype=torch.int32, device=src.device)
+    return (torch.empty(num_nodes + 1, **i32), torch.empty(e, **i32), torch.empty(e, **i32),
+            torch.empty(num_nodes + 1, **i32), torch.empty(e, **i32), torch.empty(e, **i32))
+
+
+_register("csr_build", "(Tensor src, Tensor dst, int num_nodes) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
+          _csr_build, _csr_build_fake)
+
+
+# ------------------------------------------------------------------------------------- projections
+def _proj_fwd(x, w, out_c: int, n_score: int, res_c: int, x_mask, x_scale: float):
+    hs, score, res = _lib.proj_fwd(x, w, out_c, n_score, res_c, x_mask=x_mask, x_scale=x_scale)
+    return hs, score if score is not None else _empty(x), res if res is not None else _empty(x)
+
+
+def _proj_fwd_fake(x, w, out_c, n_score, res_c, x_mask, x_scale):
+    n = x.shape[0]
+    return (x.new_empty(n, out_c), x.new_empty((n, n_score) if n_score else (0,)),
+            x.new_empty((n, res_c) if res_c else (0,)))
+
+
+_register("proj_fwd", "(Tensor x, Tensor w, int out_c, int n_score, int res_c, Tensor? x_mask, float x_scale) "
+          "-> (Tensor, Tensor, Tensor)", _proj_fwd, _proj_fwd_fake)
+
+
+def _proj_bwd_input(dy, w, add, out_mask, out_scale: float, add2, act_out, act_pre, prelu_w, want_col_sum: bool):
+    dx, cs, pg = _lib.proj_bwd_input(dy, w, add=add, out_mask=out_mask, out_scale=out_scale, add2=add2,
+                                     act_out=act_out, act_pre=act_pre, prelu_w=prelu_w, want_col_sum=want_col_sum)
+    return dx, cs if cs is not None else _empty(dy), pg if pg is not None else _empty(dy)
+
+
+def _proj_bwd_input_fake(dy, w, add, out_mask, out_scale, add2, act_out, act_pre, prelu_w, want_col_sum):
+    f = w.shape[1]
+    return (dy.new_empty(dy.shape[0], f), dy.new_empty(f if want_col_sum else 0),
+            dy.new_empty(1 if (want_col_sum and act_out is not None) else 0))
+
+
+_EPI = "Tensor? add, Tensor? out_mask, float out_scale, Tensor? add2, Tensor? act_out, Tensor? act_pre, " \
+       "Tensor? prelu_w, bool want_col_sum"
+_register("proj_bwd_input", f"(Tensor dy, Tensor w, {_EPI}) -> (Tensor, Tensor, Tensor)",
+          _proj_bwd_input, _proj_bwd_input_fake)
+
+
+def _proj_bwd_input_(dy, w, add, out_mask, out_scale: float, add2, act_out, act_pre, prelu_w, want_col_sum: bool, out):
+    _, cs, pg = _lib.proj_bwd_input(dy, w, add=add, out_mask=out_mask, out_scale=out_scale, add2=add2,
+                                    act_out=act_out, act_pre=act_pre, prelu_w=prelu_w, want_col_sum=want_col_sum,
+                                    out=out)
+    return cs if cs is not None else _empty(dy), pg if pg is not None else _empty(dy)
+
+
+def _proj_bwd_input__fake(dy, w, add, out_mask, out_scale, add2, act_out, act_pre, prelu_w, want_col_sum, out):
+    f = w.shape[1]
+    return dy.new_empty(f if want_col_sum else 0), dy.new_empty(1 if (want_col_sum and act_out is not None) else 0)
+
+
+_register("proj_bwd_input_", f"(Tensor dy, Tensor w, {_EPI}, Tensor(a!) out) -> (Tensor, Tensor)",
+          _proj_bwd_input_, _proj_bwd_input__fake)
+
+_register("proj_bwd_weight", "(Tensor dy, Tensor x, Tensor? x_mask, float x_scale) -> Tensor",
+          lambda dy, x, x_mask, x_scale: _lib.proj_bwd_weight(dy, x, x_mask=x_mask, x_scale=x_scale),
+          lambda dy, x, x_mask, x_scale: dy.new_empty(dy.shape[1], x.shape[1]))
+
+
+# ------------------------------------------------------------------------------------- GAT edge phase
+def _struct_in(n_nodes, plan7, in_src, in_dst):
+    return SimpleNamespace(num_nodes=n_nodes, num_edges=int(in_src.numel()), plan_in=_plan(*plan7), in_src=in_src,
+                           in_dst=in_dst)
+
+
+def _gat_fwd_(p0, p1, p2, p3, p4, p5, p6, in_src, in_dst, n_heads: int, head_dim: int, hs, eh, et, ee_table,
+              etype_csc, ee_csc, slope: float, bias, res, prelu_w, want_pre: bool, res_mask, res_scale: float, out):
+    s = _struct_in(out.shape[0], (p0, p1, p2, p3, p4, p5, p6), in_src, in_dst)
+    _, pre, attn = _lib.gat_fwd(s, n_heads, head_dim, hs, eh, et, ee_table, etype_csc, ee_csc, slope, bias, res,
+                                prelu_w, want_pre, res_mask=res_mask, res_scale=res_scale, out=out)
+    return pre if pre is not None else _empty(hs), attn
+
+
+def _gat_fwd__fake(p0, p1, p2, p3, p4, p5, p6, in_src, in_dst, n_heads, head_dim, hs, eh, et, ee_table, etype_csc,
+                   ee_csc, slope, bias, res, prelu_w, want_pre, res_mask, res_scale, out):
+    n, c = out.shape[0], n_heads * head_dim
+    return hs.new_empty((n, c) if want_pre else (0,)), hs.new_empty(in_src.shape[0], n_heads)
+
+
+_register("gat_fwd_", "(" + _PLAN.format("in_") + ", Tensor in_src, Tensor in_dst, int n_heads, int head_dim, "
+          "Tensor hs, Tensor eh, Tensor et, Tensor? ee_table, Tensor? etype_csc, Tensor? ee_csc, float slope, "
+          "Tensor? bias, Tensor? res, Tensor? prelu_w, bool want_pre, Tensor? res_mask, float res_scale, "
+          "Tensor(a!) out) -> (Tensor, Tensor)", _gat_fwd_, _gat_fwd__fake)
+
+
+def _gat_bwd_(i0, i1, i2, i3, i4, i5, i6, o0, o1, o2, o3, o4, o5, o6, in_src, out_dst, out_pos, n_heads: int,
+              head_dim: int, hs, attn, etype_csc, e_dim: int, slope: float, pre, act_out, prelu_w, d_out, d_pre, d_y,
+              want_bias: bool):
+    s = SimpleNamespace(num_nodes=hs.shape[0], num_edges=int(out_dst.numel()), plan_in=_plan(i0, i1, i2, i3, i4, i5, i6),
+                        plan_out=_plan(o0, o1, o2, o3, o4, o5, o6), in_src=in_src, out_dst=out_dst, out_pos=out_pos)
+    d_table, d_logit, d_bias, d_prelu = _lib.gat_bwd(s, n_heads, head_dim, hs, attn, etype_csc, e_dim, slope, pre,
+                                                     act_out, prelu_w, d_out, d_pre, d_y, want_bias)
+    e = _empty(hs)
+    return (d_table if d_table is not None else e, d_logit, d_bias if d_bias is not None else e,
+            d_prelu if d_prelu is not None else e)
+
+
+def _gat_bwd__fake(i0, i1, i2, i3, i4, i5, i6, o0, o1, o2, o3, o4, o5, o6, in_src, out_dst, out_pos, n_heads,
+                   head_dim, hs, attn, etype_csc, e_dim, slope, pre, act_out, prelu_w, d_out, d_pre, d_y, want_bias):
+    return (hs.new_empty((e_dim, n_heads) if etype_csc is not None else (0,)), hs.new_empty(out_dst.shape[0], n_heads),
+            hs.new_empty(n_heads * head_dim if want_bias else 0), hs.new_empty(1 if prelu_w is not None else 0))
+
+
+# d_pre may be the very tensor passed as d_out when prelu_w is None: both are declared mutable
+_register("gat_bwd_", "(" + _PLAN.format("in_") + ", " + _PLAN.format("out_") + ", Tensor in_src, Tensor out_dst, "
+          "Tensor out_pos, int n_heads, int head_dim, Tensor hs, Tensor attn, Tensor? etype_csc, int e_dim, "
+          "float slope, Tensor? pre, Tensor? act_out, Tensor? prelu_w, Tensor(a!) d_out, Tensor(b!) d_pre, "
+          "Tensor(c!) d_y, bool want_bias) -> (Tensor, Tensor, Tensor, Tensor)", _gat_bwd_, _gat_bwd__fake)
+
+
+def gat_fwd(struct, H, D, hs, eh, et, ee_table, etype_csc, ee_csc, slope, bias, res, prelu_w, want_pre,
+            res_mask=None, res_scale=1.0, out=None):
+    """``torch.ops.magic.gat_fwd_`` with the calling convention of ``_lib.gat_fwd`` (graph structure
+    object in, ``None`` for absent outputs)."""
+    if out is None:
+        out = torch.empty(struct.num_nodes, H * D, dtype=torch.float32, device=hs.device)
+    pre, attn = torch.ops.magic.gat_fwd_(*plan_tensors(struct.plan_in), struct.in_src, struct.in_dst, H, D, hs, eh, et,
+                                         ee_table, etype_csc, ee_csc, float(slope), bias, res, prelu_w, bool(want_pre),
+                                         res_mask, float(res_scale), out)
+    return out, _none(pre), attn
+
+
+def gat_bwd(struct, H, D, hs, attn, etype_csc, e_dim, slope, pre, act_out, prelu_w, d_out, d_pre, d_y, want_bias):
+    d_table, d_logit, d_bias, d_prelu = torch.ops.magic.gat_bwd_(
+        *plan_tensors(struct.plan_in), *plan_tensors(struct.plan_out), struct.in_src, struct.out_dst, struct.out_pos,
+        H, D, hs, attn, etype_csc, int(e_dim), float(slope), pre, act_out, prelu_w, d_out, d_pre, d_y, bool(want_bias))
+    return _none(d_table), d_logit, _none(d_bias), _none(d_prelu)
+
+
+def proj_fwd(x, w, out_c, n_score, res_c, x_mask=None, x_scale=1.0):
+    hs, score, res = torch.ops.magic.proj_fwd(x, w, out_c, n_score, res_c, x_mask, float(x_scale))
+    return hs, _none(score), _none(res)
+
+
+def proj_bwd_input(dy, w, add=None, out_mask=None, out_scale=1.0, add2=None, act_out=None, act_pre=None,
+                   prelu_w=None, want_col_sum=False, out=None):
+    if out is None:
+        dx, cs, pg = torch.ops.magic.proj_bwd_input(dy, w, add, out_mask, float(out_scale), add2, act_out, act_pre,
+                                                    prelu_w, bool(want_col_sum))
+    else:
+        dx = out
+        cs, pg = torch.ops.magic.proj_bwd_input_(dy, w, add, out_mask, float(out_scale), add2, act_out, act_pre,
+                                                 prelu_w, bool(want_col_sum), out)
+    return dx, _none(cs), _none(pg)
+
+
+def proj_bwd_weight(dy, x, x_mask=None, x_scale=1.0):
+    return torch.ops.magic.proj_bwd_weight(dy, x, x_mask, float(x_scale))
+
+
+# ------------------------------------------------------------------------------------- SCE
+def _sce_fwd_bwd(x, n_dim: int, target, single_row: bool, mask_idx, alpha: float):
+    loss, d_x, d_t = _lib.sce_fwd_bwd(x, n_dim, target, single_row, mask_idx, alpha)
+    return loss, d_x, d_t if d_t is not None else _empty(x)
+
+
+_register("sce_fwd_bwd", "(Tensor x, int n_dim, Tensor target, bool single_row, Tensor mask_idx, float alpha) "
+          "-> (Tensor, Tensor, Tensor)", _sce_fwd_bwd,
+          lambda x, n_dim, target, single_row, mask_idx, alpha:
+          (x.new_empty(1), x.new_empty(x.shape), x.new_empty(n_dim if single_row else 0)))
+
+
+def sce_fwd_bwd(x, n_dim, target, single_row, mask_idx, alpha):
+    loss, d_x, d_t = torch.ops.magic.sce_fwd_bwd(x, int(n_dim), target, bool(single_row), mask_idx, float(alpha))
+    return loss, d_x, _none(d_t)
+
+
+# magic::sce_loss: the masked SCE as a differentiable operator of its own (gradient w.r.t. x)
+def _sce_loss(x, target, mask_idx, alpha: float):
+    single = target.shape[0] == 1 and x.shape[0] != 1
+    return _lib.sce_fwd_bwd(x.contiguous(), x.shape[1], target.contiguous(), single, mask_idx, alpha)[0].view(())
+
+
+_register("sce_loss", "(Tensor x, Tensor target, Tensor mask_idx, float alpha) -> Tensor", _sce_loss,
+          lambda x, target, mask_idx, alpha: x.new_empty(()))
+
+
+def _sce_loss_setup(ctx, inputs, output):
+    x, target, mask_idx, alpha = inputs
+    ctx.save_for_backward(x, target, mask_idx)
+    ctx.alpha = alpha
+
+
+def _sce_loss_backward(ctx, g):
+    x, target, mask_idx = ctx.saved_tensors
+    single = target.shape[0] == 1 and x.shape[0] != 1
+    d_x = torch.ops.magic.sce_fwd_bwd(x.contiguous(), x.shape[1], target.contiguous(), single, mask_idx, ctx.alpha)[1]
+    return d_x * g, None, None, None
+
+
+torch.library.register_autograd("magic::sce_loss", _sce_loss_backward, setup_context=_sce_loss_setup)
+
+
+# magic::linear_nobias: y = x W^T on the projection kernels, differentiable in x and W
+_register("linear_nobias", "(Tensor x, Tensor w) -> Tensor",
+          lambda x, w: _lib.proj_fwd(x, w, w.shape[0], 0, 0)[0], lambda x, w: x.new_empty(x.shape[0], w.shape[0]))
+
+
+def _linear_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _linear_backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    dy = dy.contiguous()
+    dx = torch.ops.magic.proj_bwd_input(dy, w, None, None, 1.0, None, None, None, None, False)[0] \
+        if ctx.needs_input_grad[0] else None
+    dw = torch.ops.magic.proj_bwd_weight(dy, x, None, 1.0) if ctx.needs_input_grad[1] else None
+    return dx, dw
+
+
+torch.library.register_autograd("magic::linear_nobias", _linear_backward, setup_context=_linear_setup)
+
+
+# ------------------------------------------------------------------------------------- KNN, read-out
+def _knn_fake(train, query, k, index_offset):
+    q = query.shape[0]
+    return (torch.empty(q, k, dtype=torch.float64, device=query.device),
+            torch.empty(q, k, dtype=torch.int64, device=query.device))
+
+
+_register("knn_topk", "(Tensor train, Tensor query, int k, int index_offset) -> (Tensor, Tensor)",
+          lambda train, query, k, index_offset: _lib.knn_topk(train, query, k, index_offset), _knn_fake)
+_register("knn_merge", "(Tensor part_dist, Tensor part_idx) -> (Tensor, Tensor)",
+          lambda part_dist, part_idx: _lib.knn_merge(part_dist, part_idx),
+          lambda part_dist, part_idx: (part_dist.new_empty(part_dist.shape[1:]), part_idx.new_empty(part_idx.shape[1:])))
+_register("readout", "(Tensor feat, Tensor? node_type, int n_types, bool mean) -> Tensor",
+          lambda feat, node_type, n_types, mean: _lib.readout(feat, node_type, n_types, mean),
+          lambda feat, node_type, n_types, mean: feat.new_empty(1, max(n_types, 1) * feat.shape[1]))

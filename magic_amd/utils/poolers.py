@@ -7,9 +7,10 @@ rows side by side (``[1, n_types * hidden]``, zeros for a type without nodes) --
 over the embeddings (``magic_readout``): no Python loop over the types and no host round trip per
 type.
 """
+import torch
 import torch.nn as nn
 
-from .. import _lib
+from .. import _lib, ops  # noqa: F401  (ops registers torch.ops.magic.*)
 
 
 class Pooling(nn.Module):
@@ -28,4 +29,4 @@ class Pooling(nn.Module):
         if feat.device.type != "cuda":
             raise _lib.MagicHipError("magic_amd.Pooling runs on the MI355X only (no CPU fallback)")
         types = graph.ndata["type"] if n_types else None
-        return _lib.readout(feat, types, int(n_types or 0), self.pooler == "mean")
+        return torch.ops.magic.readout(feat, types, int(n_types or 0), self.pooler == "mean")

@@ -399,3 +399,39 @@ def test_json_dataset_files_and_labels(tmp_path):
     assert info["n_feat"] == 5 and info["e_feat"] == 3 and info["train_index"] == list(range(25, 150))
     g = ds[7][0]
     assert g.num_nodes() == 4 and g.edges()[0].tolist() == [0, 1, 2, 3] and g.edges()[1].tolist() == [1, 2, 3, 0]
+
+
+def test_custom_ops_are_registered_with_schemas_and_fake_kernels():
+    """torch.ops.magic.*: every operator resolves, has a schema, and its fake kernel infers output
+    shapes / dtypes without a GPU (FakeTensorMode); a real CPU call has no kernel."""
+    import magic_amd  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    names = ["csr_build", "proj_fwd", "proj_bwd_input", "proj_bwd_input_", "proj_bwd_weight", "gat_fwd_", "gat_bwd_",
+             "sce_fwd_bwd", "sce_loss", "linear_nobias", "knn_topk", "knn_merge", "readout"]
+    for n in names:
+        op = getattr(torch.ops.magic, n)
+        assert "magic::" + n in str(op.default._schema)
+    assert "Tensor(a!) out" in str(torch.ops.magic.gat_fwd_.default._schema)
+    with FakeTensorMode():
+        dev = "cuda"
+        n, e, h, d = 100, 400, 4, 16
+        i32 = dict(dtype=torch.int32, device=dev)
+        plan = [torch.empty(n + 1, **i32)] + [torch.empty(0, **i32) for _ in range(5)] + [torch.empty(n, **i32)]
+        f = lambda *s: torch.empty(*s, device=dev)   # noqa: E731
+        out = f(n, h * d)
+        pre, attn = torch.ops.magic.gat_fwd_(*plan, torch.empty(e, **i32), torch.empty(e, **i32), h, d, f(n, h * d),
+                                             f(n, h), f(n, h), f(17, h), torch.empty(e, **i32), None, 0.2, f(h * d),
+                                             None, f(1), True, None, 1.0, out)
+        assert pre.shape == (n, h * d) and attn.shape == (e, h)
+        ptrs = torch.ops.magic.csr_build(torch.empty(e, dtype=torch.int64, device=dev),
+                                         torch.empty(e, dtype=torch.int64, device=dev), n)
+        assert ptrs[0].shape == (n + 1,) and ptrs[1].dtype == torch.int32 and ptrs[5].shape == (e,)
+        dist, idx = torch.ops.magic.knn_topk(f(1000, 64), f(37, 64), 10, 0)
+        assert dist.shape == (37, 10) and dist.dtype == torch.float64 and idx.dtype == torch.int64
+        assert torch.ops.magic.readout(f(n, 256), torch.empty(n, dtype=torch.int64, device=dev), 8, True).shape == (1, 2048)
+        hs, score, res = torch.ops.magic.proj_fwd(f(n, 8), f(64 + 8 + 64, 8), 64, 8, 64, None, 1.0)
+        assert hs.shape == (n, 64) and score.shape == (n, 8) and res.shape == (n, 64)
+        loss, d_x, d_t = torch.ops.magic.sce_fwd_bwd(f(n, 8), 5, f(1, 5), True, torch.empty(50, dtype=torch.int64, device=dev), 3.0)
+        assert loss.shape == (1,) and d_x.shape == (n, 8) and d_t.shape == (5,)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.magic.knn_topk(torch.zeros(10, 4), torch.zeros(2, 4), 1, 0)

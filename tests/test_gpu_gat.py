@@ -342,3 +342,48 @@ def test_default_sampling_paths_equal_injected_ones(cuda):
     bg2 = union()
     bg2.edata["attr"][0, 0] += 0.0
     assert not bg2._edge_attr_marked()
+
+
+def test_custom_operators_called_directly(cuda):
+    """torch.ops.magic.gat_fwd_ / knn_topk / sce_loss / linear_nobias called as operators (not through
+    the model classes): same results as the oracle, autograd formulas of the two differentiable ones."""
+    import magic_amd
+    from magic_amd import ops
+    H, D, n_dim, e_dim = 4, 16, 5, 17
+    n, e = 400, 1700
+    src, dst, ntype, etype = small_graph(n, e, n_dim, e_dim, seed=12, hub_deg=120)
+    g = to_graph(src, dst, n, ntype, etype, n_dim, e_dim, cuda)
+    s = g.structure.ensure_csr()
+    torch.manual_seed(4)
+    hs = torch.randn(n, H * D, device=cuda)
+    eh, et = torch.randn(n, H, device=cuda), torch.randn(n, H, device=cuda)
+    table = torch.randn(e_dim, H, device=cuda)
+    bias = torch.randn(H * D, device=cuda)
+    out = torch.empty(n, H * D, device=cuda)
+    pre, attn = torch.ops.magic.gat_fwd_(*ops.plan_tensors(s.plan_in), s.in_src, s.in_dst, H, D, hs, eh, et, table,
+                                         g.edge_types_csc(), None, 0.2, bias, None, None, False, None, 1.0, out)
+    assert pre.numel() == 0 and attn.shape == (src.size, H)
+    # oracle statement of model/gat.py:302-324 on the same operands
+    S, T = torch.from_numpy(src), torch.from_numpy(dst)
+    x = (eh.cpu().double()[S] + table.cpu().double()[torch.from_numpy(etype)]) + et.cpu().double()[T]
+    a = O.edge_softmax(T, torch.nn.functional.leaky_relu(x, 0.2).unsqueeze(-1), n)
+    want = O.u_mul_e_sum(S, T, hs.cpu().double().view(n, H, D), a, n).reshape(n, H * D) + bias.cpu().double()
+    assert rel_err(out, want) < 1e-5
+    # differentiable operators
+    xw = torch.randn(300, 24, device=cuda, requires_grad=True)
+    w = torch.randn(40, 24, device=cuda, requires_grad=True)
+    y = torch.ops.magic.linear_nobias(xw, w)
+    y.square().sum().backward()
+    xr, wr = xw.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    (xr @ wr.t()).square().sum().backward()
+    assert rel_err(y, xr @ wr.t()) < 1e-5 and rel_err(xw.grad, xr.grad) < 1e-4 and rel_err(w.grad, wr.grad) < 1e-4
+    xs = torch.randn(200, 7, device=cuda, requires_grad=True)
+    tgt = torch.nn.functional.one_hot(torch.randint(0, 7, (200,)), 7).float().to(cuda)
+    mask = torch.randperm(200)[:90].to(cuda)
+    loss = torch.ops.magic.sce_loss(xs, tgt, mask, 3.0)
+    loss.backward()
+    xo = xs.detach().cpu().double().requires_grad_(True)
+    lo = O.sce_loss(xo[mask.cpu()], tgt.cpu().double()[mask.cpu()], alpha=3)
+    lo.backward()
+    assert abs(float(loss) - float(lo)) < 1e-5 and rel_err(xs.grad, xo.grad) < 1e-4
+    assert magic_amd.__version__
