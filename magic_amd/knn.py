@@ -46,13 +46,22 @@ class NearestNeighbors:
             raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, "
                              f"n_samples_fit = {self._train.shape[0]}")
         dists, idxs = [], []
-        for s in range(0, x.shape[0], self.query_block):
-            d, i = torch.ops.magic.knn_topk(self._train, x[s:s + self.query_block].contiguous(), k, index_offset)
+        block = self.query_block
+        if self._train.shape[1] > 64:
+            # rows wider than 64 take the kernel without matrix-core tiling, which keeps a
+            # [queries, train rows] float64 key matrix in its workspace: bound that matrix to 1 GiB
+            block = max(1, min(block, (1 << 30) // (8 * self._train.shape[0])))
+        for s in range(0, x.shape[0], block):
+            d, i = torch.ops.magic.knn_topk(self._train, x[s:s + block].contiguous(), k, index_offset)
             dists.append(d)
             idxs.append(i)
         if len(dists) == 1:
             return dists[0], idxs[0]
         return torch.cat(dists), torch.cat(idxs)
+
+    def mean_distances_device(self, x: torch.Tensor, n_neighbors: Optional[int] = None) -> torch.Tensor:
+        """Per-query mean of the k nearest distances (``distances.mean(axis=1)``, ``model/eval.py:313``)."""
+        return self.kneighbors_device(x, n_neighbors)[0].mean(dim=1)
 
     def kneighbors(self, x, n_neighbors: Optional[int] = None, return_distance: bool = True):
         was_numpy = isinstance(x, np.ndarray)
@@ -79,10 +88,11 @@ def merge_topk(part_dist: torch.Tensor, part_idx: torch.Tensor):
 class ShardedNearestNeighbors:
     """Train rows sharded over the process group, queries replicated.
 
-    Rank r keeps rows ``[r*ceil(N/G), (r+1)*ceil(N/G))``.  ``kneighbors_device`` computes the
-    local top-k with global indices, all-gathers the ``[Q,k]`` lists (Q*k*16 bytes per rank;
-    one collective, all xGMI links busy at once) and merges them in shard order, which
-    reproduces the single-device (distance, index) ordering exactly.
+    Rank r keeps rows ``[r*ceil(N/G), (r+1)*ceil(N/G))``.  Every rank computes the local top-k of
+    all queries with global indices; one all-to-all hands rank r the G partial lists of query
+    block r, which it merges in shard order -- the single-device (distance, index) ordering
+    exactly.  ``mean_distances_device`` then all-gathers only the ``[Q]`` per-query means;
+    ``kneighbors_device`` all-gathers the merged lists for callers that need them everywhere.
     """
 
     def __init__(self, n_neighbors: int, group=None, device="cuda", local=None):
@@ -134,20 +144,57 @@ class ShardedNearestNeighbors:
         return d, i
 
     def kneighbors_device(self, xq: torch.Tensor, n_neighbors: Optional[int] = None):
+        """Global ``(distances, indices)`` of all queries on every rank."""
         k = n_neighbors or self.k
         d, i = self.local_topk(xq, k)
-        return exchange_and_merge(d, i, self.group)
+        md, mi, q = exchange_and_merge_blocks(d, i, self.group)
+        return gather_blocks(md, q, self.group), gather_blocks(mi, q, self.group)
+
+    def mean_distances_device(self, xq: torch.Tensor, n_neighbors: Optional[int] = None) -> torch.Tensor:
+        """Per-query mean of the k nearest distances (``distances.mean(axis=1)`` at ``model/eval.py:313``)
+        on every rank: the merged lists stay with the rank that merged them, only the ``[Q]`` means travel."""
+        k = n_neighbors or self.k
+        d, i = self.local_topk(xq, k)
+        md, _, q = exchange_and_merge_blocks(d, i, self.group)
+        return gather_blocks(md.mean(dim=1), q, self.group)
 
 
-def exchange_and_merge(d: torch.Tensor, i: torch.Tensor, group=None):
-    """All-gather the per-rank ``[Q,k]`` lists and merge them (works for gloo/CPU and RCCL)."""
+def exchange_and_merge_blocks(d: torch.Tensor, i: torch.Tensor, group=None):
+    """One all-to-all: the queries are cut into ``world`` blocks of ``ceil(Q / world)`` rows and rank r
+    receives every rank's partial top-k lists of block r (``(Q / world) * k * 16`` bytes per peer, all
+    xGMI links busy at once), then merges them in shard order -- the single-device (distance, index)
+    order.  Returns the merged ``[ceil(Q / world), k]`` lists of this rank's block (rows past Q are
+    padding) and Q."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    q, k = d.shape
+    if world == 1:
+        return d, i, q
+    per = (q + world - 1) // world
+    pad = per * world - q
+    if pad:
+        d = torch.cat([d, torch.full((pad, k), float("inf"), dtype=d.dtype, device=d.device)])
+        i = torch.cat([i, torch.full((pad, k), -1, dtype=i.dtype, device=i.device)])
+    rd, ri = torch.empty_like(d), torch.empty_like(i)
+    dist.all_to_all_single(rd, d.contiguous(), group=group)     # chunk j of the send buffer goes to rank j
+    dist.all_to_all_single(ri, i.contiguous(), group=group)
+    md, mi = merge_topk(rd.view(world, per, k), ri.view(world, per, k))
+    return md, mi, q
+
+
+def gather_blocks(block: torch.Tensor, q: int, group=None) -> torch.Tensor:
+    """All-gather of the ranks' row blocks, cut back to the first ``q`` rows."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if world == 1:
-        return d, i
-    q, k = d.shape
-    pd = torch.empty((world * q, k), dtype=d.dtype, device=d.device)
-    pi = torch.empty((world * q, k), dtype=i.dtype, device=i.device)
-    dist.all_gather_into_tensor(pd, d.contiguous(), group=group)
-    dist.all_gather_into_tensor(pi, i.contiguous(), group=group)
-    return merge_topk(pd.view(world, q, k), pi.view(world, q, k))
+        return block[:q]
+    out = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(out, block.contiguous(), group=group)
+    return out[:q]
+
+
+def exchange_and_merge(d: torch.Tensor, i: torch.Tensor, group=None):
+    """Global ``[Q,k]`` lists on every rank from the per-rank partial lists (all-to-all, merge of
+    Q / world queries per rank, all-gather of the merged blocks)."""
+    md, mi, q = exchange_and_merge_blocks(d, i, group)
+    return gather_blocks(md, q, group), gather_blocks(mi, q, group)

@@ -1,14 +1,20 @@
 """KNN outlier detector with the reference's API (``model/eval.py``).
 
-Signatures, printed lines, cache file and metric tail follow the reference; the distance
-search -- scikit-learn's ``NearestNeighbors`` there (``model/eval.py:150-158``, ``:294-311``)
--- runs on the MI355X (``magic_amd.knn``).  Standardisation is done in numpy exactly as
-the reference does it, so the search sees bit-identical inputs.
+Signatures, printed lines and metric tail follow the reference; the distance search --
+scikit-learn's ``NearestNeighbors`` there (``model/eval.py:150-158``, ``:294-311``) -- runs on the
+MI355X (``magic_amd.knn``).  With numpy inputs (the reference's call shape) standardisation is done
+in numpy exactly as the reference does it, so the search sees bit-identical inputs; with embeddings
+that already live on the GPU (``entity_level_distances`` on CUDA tensors) standardisation, both
+searches and the row means stay on the device.
+
+The result cache of the entity-level evaluator (``model/eval.py:298-320``) is kept, but as an
+``.npz`` file that is read without unpickling and only accepted for the very arrays it was computed
+from; the reference's ``.pkl`` cache files are never opened.
 """
 from __future__ import annotations
 
+import hashlib
 import os
-import pickle as pkl
 import random
 
 import numpy as np
@@ -138,9 +144,55 @@ def evaluate_batch_level_using_knn(repeat, dataset, embeddings, labels):
     return auc, 0.0
 
 
-def entity_level_distances(x_train, x_test, n_neighbors, nbrs=None):
+def _mean_k_distance(nbrs, x, n_neighbors):
+    """Per-row mean of the k nearest distances, on the device."""
+    if hasattr(nbrs, "mean_distances_device"):
+        return nbrs.mean_distances_device(x, n_neighbors)
+    return nbrs.kneighbors_device(x, n_neighbors)[0].mean(dim=1)
+
+
+def standardise_device(x_train: torch.Tensor, x_test: torch.Tensor, sharded: bool = False, group=None):
+    """``(x - mean) / std`` with the train columns' mean and (population) standard deviation
+    (``model/eval.py:282-285``: no epsilon), statistics accumulated in float64 and rounded to float32
+    once, the division in float32 as numpy does it.  With ``sharded`` the rows of ``x_train`` are one
+    rank's shard and the column sums are all-reduced over ``group`` (two ``[d]`` float64 vectors)."""
+    n = torch.tensor([float(x_train.shape[0])], dtype=torch.float64, device=x_train.device)
+    s1 = x_train.sum(0, dtype=torch.float64)
+    if sharded:
+        import torch.distributed as dist
+        dist.all_reduce(s1, group=group)
+        dist.all_reduce(n, group=group)
+    mean = (s1 / n).float()
+    s2 = (x_train - mean).square_().sum(0, dtype=torch.float64)
+    if sharded:
+        dist.all_reduce(s2, group=group)
+    std = (s2 / n).sqrt().float()
+    return (x_train - mean) / std, (x_test - mean) / std
+
+
+def _entity_level_distances_device(x_train, x_test, n_neighbors, nbrs=None, sample_idx=None):
+    x_train, x_test = standardise_device(x_train.float(), x_test.float())
+    if nbrs is None:
+        nbrs = NearestNeighbors(n_neighbors=n_neighbors, device=x_train.device)
+    nbrs.fit(x_train)
+    if sample_idx is None:
+        idx = list(range(x_train.shape[0]))
+        random.shuffle(idx)                                     # model/eval.py:303-304
+        sample_idx = idx[:min(50000, x_train.shape[0])]
+    sample_idx = torch.as_tensor(sample_idx, dtype=torch.int64).to(x_train.device, non_blocking=True)
+    mean_distance = _mean_k_distance(nbrs, x_train[sample_idx], n_neighbors).mean()
+    return mean_distance, _mean_k_distance(nbrs, x_test, n_neighbors)
+
+
+def entity_level_distances(x_train, x_test, n_neighbors, nbrs=None, sample_idx=None):
     """Hot lines of ``model/eval.py:282-313``: standardise, mean k-NN distance of at most
-    50,000 shuffled train rows, per-test-row mean k-NN distance."""
+    50,000 shuffled train rows, per-test-row mean k-NN distance.
+
+    numpy arrays in (the reference's call shape): numpy standardisation, numpy results.  CUDA tensors
+    in: everything stays on the device and the results are float64 device tensors.  ``sample_idx``
+    replaces the ``random.shuffle`` draw of the train rows behind ``mean_distance``."""
+    if isinstance(x_train, torch.Tensor) and x_train.device.type == "cuda":
+        return _entity_level_distances_device(x_train, x_test, n_neighbors, nbrs, sample_idx)
     x_train_mean = x_train.mean(axis=0)
     x_train_std = x_train.std(axis=0)
     x_train = (x_train - x_train_mean) / x_train_std
@@ -148,27 +200,54 @@ def entity_level_distances(x_train, x_test, n_neighbors, nbrs=None):
     if nbrs is None:
         nbrs = NearestNeighbors(n_neighbors=n_neighbors, n_jobs=-1)
     nbrs.fit(x_train)
-    idx = list(range(x_train.shape[0]))
-    random.shuffle(idx)
-    distances, _ = nbrs.kneighbors(x_train[idx][:min(50000, x_train.shape[0])], n_neighbors=n_neighbors)
+    if sample_idx is None:
+        idx = list(range(x_train.shape[0]))
+        random.shuffle(idx)
+        sample_idx = idx[:min(50000, x_train.shape[0])]
+    distances, _ = nbrs.kneighbors(x_train[sample_idx], n_neighbors=n_neighbors)
     mean_distance = distances.mean()
     distances, _ = nbrs.kneighbors(x_test, n_neighbors=n_neighbors)
     return mean_distance, distances.mean(axis=1)
+
+
+def _fingerprint(x_train, x_test, n_neighbors) -> str:
+    """Identity of the arrays a cached result belongs to (shapes, dtypes, neighbour count, bytes)."""
+    h = hashlib.sha256()
+    for a in (x_train, x_test):
+        a = np.ascontiguousarray(a)
+        h.update(repr((a.shape, str(a.dtype), int(n_neighbors))).encode())
+        h.update(memoryview(a).cast("B"))
+    return h.hexdigest()
+
+
+def _load_distance_cache(path, fingerprint, n_test):
+    """(mean_distance, distances) from a cache this module wrote for exactly these inputs, else None.
+    ``numpy.load`` without pickle support: nothing in the file is executed."""
+    if not os.path.exists(path):
+        return None
+    try:
+        with np.load(path, allow_pickle=False) as z:
+            if str(z["fingerprint"]) != fingerprint or z["distances"].shape != (n_test,):
+                return None
+            return float(z["mean_distance"]), np.array(z["distances"], dtype=np.float64)
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def evaluate_entity_level_using_knn(dataset, x_train, x_test, y_test):
     """``model/eval.py:265-367``."""
     roc_auc_score, precision_recall_curve = _metrics()
     n_neighbors = 200 if dataset == 'cadets' else 10
-    save_dict_path = './eval_result/distance_save_{}.pkl'.format(dataset)
-    if not os.path.exists(save_dict_path):
+    save_dict_path = './eval_result/distance_save_{}.npz'.format(dataset)
+    fingerprint = _fingerprint(x_train, x_test, n_neighbors)
+    cached = _load_distance_cache(save_dict_path, fingerprint, len(y_test))
+    if cached is None:
         mean_distance, distances = entity_level_distances(x_train, x_test, n_neighbors)
         os.makedirs(os.path.dirname(save_dict_path), exist_ok=True)
-        with open(save_dict_path, 'wb') as f:
-            pkl.dump([mean_distance, distances], f)
+        np.savez(save_dict_path, mean_distance=np.float64(mean_distance), distances=np.asarray(distances, np.float64),
+                 fingerprint=np.str_(fingerprint))
     else:
-        with open(save_dict_path, 'rb') as f:  # a cache this function wrote itself
-            mean_distance, distances = pkl.load(f)
+        mean_distance, distances = cached
     score = distances / mean_distance
     del distances
     auc = roc_auc_score(y_test, score)

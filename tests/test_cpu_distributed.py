@@ -151,7 +151,10 @@ def _entity_worker(rank, world, port, out):
     random.seed(3)
     nbrs = ShardedNearestNeighbors(10, device="cpu", local=_HostSearch())
     mean_distance, distances = entity_level_distances(x_train, x_test, 10, nbrs=nbrs)
-    np.savez(f"{out}/ent{rank}.npz", m=mean_distance, d=distances)
+    # per-query means only (all-to-all, merge of this rank's query block, all-gather of [Q] means)
+    xs = (x_test - x_train.mean(0)) / x_train.std(0)
+    means = nbrs.mean_distances_device(torch.from_numpy(xs), 10).numpy()
+    np.savez(f"{out}/ent{rank}.npz", m=mean_distance, d=distances, means=means)
     dist.destroy_process_group()
 
 
@@ -169,6 +172,7 @@ def test_entity_level_scores_sharded_equal_single_world2(tmp_path):
         got = np.load(tmp_path / f"ent{r}.npz")
         assert float(got["m"]) == float(m)
         assert np.array_equal(got["d"], d)
+        assert got["means"].shape == (57,) and np.allclose(got["means"], d, rtol=1e-13, atol=0)   # 57 queries: ragged blocks
 
 
 class _FakeGraph:

@@ -137,3 +137,36 @@ def test_sce_zero_token_target(cuda):
     assert float(lm) == pytest.approx(1.0, abs=1e-6)
     assert rel_err(tm.grad, to.grad) < 1e-4
     assert rel_err(xm.grad, xo.grad) < 1e-4 or float(xo.grad.abs().max()) == 0.0
+
+
+def test_knn_wide_rows_many_train_rows_are_searched_in_blocks(cuda):
+    """d = 128 takes the kernel that keeps a [queries, train rows] key matrix; NearestNeighbors cuts the
+    queries so that this matrix stays bounded (60,000 train rows: 2,236 queries per call)."""
+    from magic_amd.knn import NearestNeighbors
+    rng = np.random.default_rng(5)
+    train = rng.standard_normal((60000, 128)).astype(np.float32)
+    query = rng.standard_normal((5000, 128)).astype(np.float32)
+    nn_ = NearestNeighbors(10, device=cuda).fit(train)
+    torch.cuda.reset_peak_memory_stats()
+    d, i = nn_.kneighbors(query[:5000], 10)
+    assert torch.cuda.max_memory_allocated() < 3 * (1 << 30)
+    wd, wi = knn_oracle.exact_topk(train, query[:300], 10)
+    assert np.array_equal(i[:300], wi) and np.abs(d[:300] - wd).max() < 1e-6
+    assert (np.diff(d, axis=1) >= 0).all()
+
+
+def test_entity_level_scoring_on_device_equals_host_standardisation(cuda):
+    """model/eval.py:282-313 with CUDA tensors in (standardise + both searches + row means on the
+    device) against the numpy-standardised path of the same function."""
+    import random
+    from magic_amd import synth
+    from magic_amd.model.eval import entity_level_distances
+    x_train = synth.gaussian_mixture(30000, 64, seed=3) * 2.5 + 0.7
+    x_test = synth.gaussian_mixture(4000, 64, seed=4) * 2.5 + 0.7
+    random.seed(9)
+    m_host, d_host = entity_level_distances(x_train, x_test, 10)
+    random.seed(9)
+    m_dev, d_dev = entity_level_distances(torch.from_numpy(x_train).to(cuda), torch.from_numpy(x_test).to(cuda), 10)
+    assert d_dev.dtype == torch.float64 and d_dev.device.type == "cuda"
+    assert abs(float(m_dev) - float(m_host)) < 1e-5 * float(m_host)
+    assert np.abs(d_dev.cpu().numpy() - d_host).max() < 1e-5 * np.abs(d_host).max()

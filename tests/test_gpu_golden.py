@@ -50,11 +50,22 @@ def test_entity_level_evaluator_equals_reference(cuda, ds, tmp_path, monkeypatch
         auc = ev.evaluate_entity_level_using_knn(ds, z[f"{ds}_x_train"].copy(), z[f"{ds}_x_test"].copy(),
                                                  z[f"{ds}_y_test"])[0]
     assert abs(auc - float(z[f"{ds}_auc"])) < 1e-9
-    import pickle
-    with open(tmp_path / "eval_result" / f"distance_save_{ds}.pkl", "rb") as f:     # written by the call above
-        mean_distance, dists = pickle.load(f)
+    with np.load(tmp_path / "eval_result" / f"distance_save_{ds}.npz", allow_pickle=False) as c:   # written by the call above
+        mean_distance, dists = float(c["mean_distance"]), c["distances"]
     assert abs(mean_distance - float(z[f"{ds}_mean_distance"])) < 1e-6
     assert np.abs(dists - z[f"{ds}_dists"]).max() < 2e-6
+    # a second call is served from the cache; a cache of other arrays, or a reference-style .pkl file, is not used
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert ev.evaluate_entity_level_using_knn(ds, z[f"{ds}_x_train"].copy(), z[f"{ds}_x_test"].copy(),
+                                                  z[f"{ds}_y_test"])[0] == auc
+        (tmp_path / "eval_result" / f"distance_save_{ds}.pkl").write_bytes(b"not a pickle this code would ever open")
+        x_other = z[f"{ds}_x_test"].copy()
+        x_other[0, 0] += 1.0
+        random.seed(1234)
+        auc_other = ev.evaluate_entity_level_using_knn(ds, z[f"{ds}_x_train"].copy(), x_other, z[f"{ds}_y_test"])[0]
+    assert np.isfinite(auc_other)
+    with np.load(tmp_path / "eval_result" / f"distance_save_{ds}.npz", allow_pickle=False) as c:
+        assert not np.array_equal(c["distances"], dists)          # recomputed for the new arrays
     # same printed metric lines (scraped by the reference's web wrapper)
     want = str(z[f"{ds}_stdout"]).strip().splitlines()
     got = buf.getvalue().strip().splitlines()
