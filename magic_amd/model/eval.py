@@ -234,10 +234,34 @@ def _load_distance_cache(path, fingerprint, n_test):
         return None
 
 
+def _print_entity_metrics(m):
+    """The lines ``model/eval.py:359-366`` prints (scraped by the reference's web wrapper)."""
+    print('AUC: {}'.format(m["auc"]))
+    print('F1: {}'.format(m["f1"]))
+    print('PRECISION: {}'.format(m["precision"]))
+    print('RECALL: {}'.format(m["recall"]))
+    print('TN: {}'.format(m["tn"]))
+    print('FN: {}'.format(m["fn"]))
+    print('TP: {}'.format(m["tp"]))
+    print('FP: {}'.format(m["fp"]))
+
+
 def evaluate_entity_level_using_knn(dataset, x_train, x_test, y_test):
-    """``model/eval.py:265-367``."""
-    roc_auc_score, precision_recall_curve = _metrics()
+    """``model/eval.py:265-367``.
+
+    numpy arrays in (the reference's call shape): numpy standardisation, the fingerprinted ``.npz``
+    result cache, scikit-learn's curve functions.  CUDA tensors in: standardisation, both searches,
+    the score and the whole metric tail (AUC, precision-recall curve, recall floor, confusion counts:
+    ``model/metrics.py``) run on the device, nothing is cached, and only the printed numbers reach
+    the host."""
     n_neighbors = 200 if dataset == 'cadets' else 10
+    if isinstance(x_train, torch.Tensor) and x_train.device.type == "cuda":
+        from .metrics import entity_level_detection_metrics
+        mean_distance, distances = entity_level_distances(x_train, x_test, n_neighbors)
+        m = entity_level_detection_metrics(dataset, torch.as_tensor(y_test), distances / mean_distance)
+        _print_entity_metrics(m)
+        return m["auc"], 0.0, None, None
+    roc_auc_score, precision_recall_curve = _metrics()
     save_dict_path = './eval_result/distance_save_{}.npz'.format(dataset)
     fingerprint = _fingerprint(x_train, x_test, n_neighbors)
     cached = _load_distance_cache(save_dict_path, fingerprint, len(y_test))
@@ -261,12 +285,40 @@ def evaluate_entity_level_using_knn(dataset, x_train, x_test, y_test):
             break
     best_thres = threshold[best_idx]
     tn, fn, tp, fp = _confusion(y_test, score, best_thres)
-    print('AUC: {}'.format(auc))
-    print('F1: {}'.format(f1[best_idx]))
-    print('PRECISION: {}'.format(prec[best_idx]))
-    print('RECALL: {}'.format(rec[best_idx]))
-    print('TN: {}'.format(tn))
-    print('FN: {}'.format(fn))
-    print('TP: {}'.format(tp))
-    print('FP: {}'.format(fp))
+    _print_entity_metrics(dict(auc=auc, f1=f1[best_idx], precision=prec[best_idx], recall=rec[best_idx],
+                               tn=tn, fn=fn, tp=tp, fp=fp))
     return auc, 0.0, None, None
+
+
+def entity_level_evaluation(model, dataset, device, metadata=None, load_graph=None):
+    """The entity-level branch of the reference's evaluation driver (``eval.py:62-121``) without a
+    host round trip: embed every train and test graph (``model.embed``), build the test set
+    (``eval.py:99-114``: the last test graph's nodes plus every malicious node), score it against the
+    train embeddings and print the metrics -- embeddings, search and metric tail stay on the GPU.
+
+    ``metadata`` / ``load_graph(kind, i)`` default to ``utils.loaddata.load_metadata(dataset)`` and
+    ``load_entity_level_dataset(dataset, kind, i)``.  Returns (test_auc, test_std)."""
+    from ..utils import loaddata
+    from .metrics import entity_level_test_set
+    if metadata is None:
+        metadata = loaddata.load_metadata(dataset)
+    if load_graph is None:
+        def load_graph(kind, i):
+            return loaddata.load_entity_level_dataset(dataset, kind, i)
+    model.eval()
+    malicious, _ = metadata['malicious']
+    n_train, n_test = metadata['n_train'], metadata['n_test']
+    with torch.no_grad():
+        x_train = torch.cat([model.embed(load_graph('train', i).to(device)) for i in range(n_train)], 0)
+        skip_benign = 0
+        x_test = []
+        for i in range(n_test):
+            g = load_graph('test', i).to(device)
+            if i != n_test - 1:
+                skip_benign += g.number_of_nodes()
+            x_test.append(model.embed(g))
+            del g
+        x_test, y_test = entity_level_test_set(torch.cat(x_test, 0), malicious, skip_benign)
+        test_auc, test_std, _, _ = evaluate_entity_level_using_knn(dataset, x_train, x_test, y_test)
+    print(f"#Test_AUC: {test_auc:.4f}±{test_std:.4f}")
+    return test_auc, test_std

@@ -7,9 +7,21 @@ node-link JSON graphs the reference's parsers write (``utils/streamspot_parser.p
 node_attrs=['type'], edge_attrs=['type'])`` builds at ``utils/loaddata.py:62-66`` and ``:141-145``
 -- same node numbering, same edge order -- and the two batch-level datasets on top of it.  The
 reference's ``graphs.pkl`` / ``train{i}.pkl`` caches are pickled DGL objects and are not read.
+
+Entity-level datasets (DARPA E3 Trace / THEIA / CADETS): the trace parser leaves ``train.pkl`` and
+``test.pkl`` (lists of ``networkx.node_link_data`` dictionaries) and ``malicious.pkl`` (ids and names of
+the malicious test nodes) under ``./data/<name>/`` (``utils/trace_parser.py:235-237``).  They hold plain
+containers, numbers and strings only, so they are read with an unpickler that refuses every global
+(no code in the file can run).  ``preload_entity_level_dataset`` / ``load_metadata`` /
+``load_entity_level_dataset`` keep the reference's names and ``metadata.json`` layout
+(``utils/loaddata.py:263-363``); the per-graph cache is an ``.npz`` file of int32 arrays
+(edge list, types, and the CSC / CSR arrays once they were built) instead of a pickled DGL object.
 """
 import json
 import os
+import pickle
+
+import numpy as np
 
 import torch
 import torch.nn.functional as F
@@ -116,3 +128,79 @@ def load_json_dataset(name: str, root: str = "./data"):
     dataset = [(load_node_link_json(f), y) for f, y in zip(files, labels)]
     register_batch_level_dataset(name, dataset)
     return dataset
+
+
+# ------------------------------------------------------------------------------------- entity level
+class _PlainUnpickler(pickle.Unpickler):
+    """Unpickler for files that hold only containers, numbers and strings: any reference to a class or
+    function (the only way a pickle can run code) is refused."""
+
+    def find_class(self, module, name):
+        raise pickle.UnpicklingError(f"global '{module}.{name}' is not allowed in a MAGIC data file")
+
+
+def load_plain_pickle(path: str):
+    with open(path, "rb") as f:
+        return _PlainUnpickler(f).load()
+
+
+def save_graph_npz(g: Graph, path: str):
+    """int32 binary cache of one graph: edge list, node / edge types and, if built, the CSC / CSR arrays."""
+    s = g.structure
+    arrays = {"num_nodes": np.int64(s.num_nodes), "src": s.src.cpu().numpy().astype(np.int32),
+              "dst": s.dst.cpu().numpy().astype(np.int32),
+              "ntype": g.ndata["type"].cpu().numpy().astype(np.int32),
+              "etype": g.edata["type"].cpu().numpy().astype(np.int32)}
+    if s.has_csr():
+        for k in ("in_ptr", "in_src", "in_eid", "out_ptr", "out_dst", "out_eid"):
+            arrays[k] = getattr(s, k).cpu().numpy().astype(np.int32)
+    np.savez(path, **arrays)
+
+
+def load_graph_npz(path: str) -> Graph:
+    with np.load(path, allow_pickle=False) as z:
+        g = Graph(torch.from_numpy(z["src"].astype(np.int64)), torch.from_numpy(z["dst"].astype(np.int64)),
+                  int(z["num_nodes"]))
+        g.ndata["type"] = torch.from_numpy(z["ntype"].astype(np.int64))
+        g.edata["type"] = torch.from_numpy(z["etype"].astype(np.int64))
+        if "in_ptr" in z.files:
+            g.structure.set_csr(*(torch.from_numpy(z[k]) for k in
+                                  ("in_ptr", "in_src", "in_eid", "out_ptr", "out_dst", "out_eid")))
+    return g
+
+
+def preload_entity_level_dataset(path, root: str = "./data"):
+    """``utils/loaddata.py:263-326``: on first use turn ``train.pkl`` / ``test.pkl`` / ``malicious.pkl``
+    into ``metadata.json`` (same keys as the reference writes) and one ``train{i}.npz`` / ``test{i}.npz``
+    per graph."""
+    base = os.path.join(root, path)
+    if os.path.exists(os.path.join(base, "metadata.json")) and os.path.exists(os.path.join(base, "train0.npz")):
+        return
+    train_gs = [graph_from_node_link(d) for d in load_plain_pickle(os.path.join(base, "train.pkl"))]
+    test_gs = [graph_from_node_link(d) for d in load_plain_pickle(os.path.join(base, "test.pkl"))]
+    malicious = load_plain_pickle(os.path.join(base, "malicious.pkl"))
+    node_feature_dim = max(int(g.ndata["type"].max()) for g in train_gs + test_gs) + 1
+    edge_feature_dim = max(int(g.edata["type"].max()) for g in train_gs + test_gs) + 1
+    metadata = {"node_feature_dim": node_feature_dim, "edge_feature_dim": edge_feature_dim,
+                "malicious": [list(malicious[0]), list(malicious[1])],
+                "n_train": len(train_gs), "n_test": len(test_gs)}
+    for kind, gs in (("train", train_gs), ("test", test_gs)):
+        for i, g in enumerate(gs):
+            save_graph_npz(g, os.path.join(base, f"{kind}{i}.npz"))
+    with open(os.path.join(base, "metadata.json"), "w", encoding="utf-8") as f:
+        json.dump(metadata, f)
+
+
+def load_metadata(path, root: str = "./data"):
+    """``utils/loaddata.py:328-344``."""
+    preload_entity_level_dataset(path, root)
+    with open(os.path.join(root, path, "metadata.json"), "r", encoding="utf-8") as f:
+        return json.load(f)
+
+
+def load_entity_level_dataset(path, t, n, root: str = "./data") -> Graph:
+    """``utils/loaddata.py:346-363``: the n-th ``t`` ('train' | 'test') graph with one-hot attributes
+    (the reference caches its graphs after ``transform_graph``)."""
+    meta = load_metadata(path, root)
+    g = load_graph_npz(os.path.join(root, path, f"{t}{n}.npz"))
+    return transform_graph(g, meta["node_feature_dim"], meta["edge_feature_dim"])

@@ -435,3 +435,85 @@ def test_custom_ops_are_registered_with_schemas_and_fake_kernels():
         assert loss.shape == (1,) and d_x.shape == (n, 8) and d_t.shape == (5,)
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.magic.knn_topk(torch.zeros(10, 4), torch.zeros(2, 4), 1, 0)
+
+
+# ----------------------------------------------------------------------------- detection tail, loaders
+def test_device_metric_tail_equals_sklearn_and_the_reference_loop():
+    """model/metrics.py (torch sort + scan) against scikit-learn's roc_auc_score / precision_recall_curve
+    and the threshold walk + confusion loop of model/eval.py:327-357, with and without tied scores."""
+    from sklearn.metrics import precision_recall_curve, roc_auc_score
+    from magic_amd.model import metrics as M
+    rng = np.random.default_rng(0)
+    for trial, ds in enumerate(["trace", "theia", "cadets", "fivedirections"]):
+        n = 6000
+        y = (rng.random(n) < 0.05).astype(np.float64)
+        s = rng.standard_normal(n) + 4.0 * y
+        if trial % 2:
+            s = np.round(s, 1)
+        ys, ss = torch.from_numpy(y), torch.from_numpy(s)
+        assert abs(float(M.roc_auc(ys, ss)) - roc_auc_score(y, s)) < 1e-12
+        p, r, t = precision_recall_curve(y, s)
+        p2, r2, t2 = M.precision_recall_curve(ys, ss)
+        assert np.array_equal(t, t2.numpy()) and np.allclose(p, p2.numpy(), atol=1e-15) and np.allclose(r, r2.numpy(), atol=1e-15)
+        f1 = 2 * p * r / (r + p + 1e-9)
+        best = -1
+        for i in range(len(f1)):                      # model/eval.py:331-341
+            if ds in M.RECALL_FLOOR and r[i] < M.RECALL_FLOOR[ds]:
+                best = i - 1
+                break
+        thr = t[best]
+        want = dict(tp=int(((y == 1) & (s >= thr)).sum()), fn=int(((y == 1) & (s < thr)).sum()),
+                    tn=int(((y == 0) & (s < thr)).sum()), fp=int(((y == 0) & (s >= thr)).sum()))
+        got = M.entity_level_detection_metrics(ds, ys, ss)
+        assert {k: got[k] for k in want} == want and got["threshold"] == thr
+        assert abs(got["f1"] - f1[best]) < 1e-12 and abs(got["recall"] - r[best]) < 1e-15
+    # eval.py:99-114
+    x = torch.arange(40.).view(10, 4)
+    xs, ys = M.entity_level_test_set(x, [1, 7], 6)
+    assert xs[:, 0].tolist() == [4.0, 24.0, 28.0, 32.0, 36.0] and ys.tolist() == [1.0, 0.0, 1.0, 0.0, 0.0]
+
+
+def test_entity_level_loaders_read_the_parser_outputs(tmp_path):
+    """train.pkl / test.pkl / malicious.pkl as utils/trace_parser.py:235-237 writes them (networkx
+    node-link dictionaries) -> metadata.json with the reference's keys + per-graph npz caches; a pickle
+    that references any global is refused."""
+    import json
+    import pickle
+    import networkx as nx
+    from magic_amd.utils import loaddata as L
+    rng = np.random.default_rng(3)
+
+    def make(n, e):
+        g = nx.DiGraph()
+        for i in rng.permutation(n):
+            g.add_node(int(i), type=int(rng.integers(0, 6)))
+        for _ in range(e):
+            u, v = int(rng.integers(0, n)), int(rng.integers(0, n))
+            g.add_edge(u, v, type=int(rng.integers(0, 9)))
+        return g
+    base = tmp_path / "data" / "toy"
+    base.mkdir(parents=True)
+    train, test = [make(30, 80), make(25, 60)], [make(40, 90)]
+    pickle.dump([nx.node_link_data(g) for g in train], open(base / "train.pkl", "wb"))
+    pickle.dump([nx.node_link_data(g) for g in test], open(base / "test.pkl", "wb"))
+    pickle.dump(([3, 17], ["a", "b"]), open(base / "malicious.pkl", "wb"))
+    root = str(tmp_path / "data")
+    meta = L.load_metadata("toy", root=root)
+    assert set(meta) == {"node_feature_dim", "edge_feature_dim", "malicious", "n_train", "n_test"}
+    assert meta["n_train"] == 2 and meta["n_test"] == 1 and meta["malicious"] == [[3, 17], ["a", "b"]]
+    assert json.load(open(base / "metadata.json"))["node_feature_dim"] == meta["node_feature_dim"]
+    for kind, gs in (("train", train), ("test", test)):
+        for i, gx in enumerate(gs):
+            g = L.load_entity_level_dataset("toy", kind, i, root=root)
+            want = L.graph_from_node_link(nx.node_link_data(gx))
+            assert torch.equal(g.edges()[0], want.edges()[0]) and torch.equal(g.edges()[1], want.edges()[1])
+            assert torch.equal(g.ndata["type"], want.ndata["type"]) and torch.equal(g.edata["type"], want.edata["type"])
+            assert g.ndata["attr"].shape == (g.num_nodes(), meta["node_feature_dim"])
+            assert g.edata["attr"].shape == (g.num_edges(), meta["edge_feature_dim"])
+            # same node numbering / edge order as dgl.from_networkx: sorted node labels, DiGraph edge order
+            nodes = sorted(gx.nodes())
+            assert [(nodes.index(u), nodes.index(v)) for u, v in gx.edges()] == \
+                list(zip(g.edges()[0].tolist(), g.edges()[1].tolist()))
+    pickle.dump([np.arange(3)], open(base / "evil.pkl", "wb"))          # needs numpy globals to load
+    with pytest.raises(pickle.UnpicklingError):
+        L.load_plain_pickle(str(base / "evil.pkl"))

@@ -117,3 +117,53 @@ def test_theia_checkpoint_embeddings(cuda):
         want = copy.deepcopy(ref).double().eval().embed(to_ograph(src, dst, n, nt, et, 5, 17, torch.float64))
         got = mine.to(cuda).eval().embed(to_graph(src, dst, n, nt, et, 5, 17, cuda))
     assert rel_err(got, want) < 1e-4
+
+
+def test_entity_level_evaluation_on_device_equals_host_pipeline(cuda, tmp_path, monkeypatch):
+    """eval.py:62-121 end to end: embeddings -> test set -> KNN scores -> metric tail, everything on the
+    GPU, against the same model's embeddings pushed through the numpy-shaped evaluator (whose arithmetic
+    the reference-generated fixtures above pin): same confusion counts, same AUC."""
+    from magic_amd import synth
+    from magic_amd.model import eval as ev
+    from magic_amd.model.autoencoder import GMAEModel
+    monkeypatch.chdir(tmp_path)
+    n_dim, e_dim = 5, 17
+    torch.manual_seed(2)
+    model = GMAEModel(n_dim, e_dim, 64, 3, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(cuda).eval()
+    graphs = {("train", 0): synth.make_graph(3000, 9000, n_dim, e_dim, seed=1),
+              ("train", 1): synth.make_graph(2500, 8000, n_dim, e_dim, seed=2),
+              ("test", 0): synth.make_graph(2000, 6000, n_dim, e_dim, seed=3),
+              ("test", 1): synth.make_graph(2600, 8000, n_dim, e_dim, seed=4)}
+    rng = np.random.default_rng(0)
+    malicious = sorted(rng.choice(4600, 60, replace=False).tolist())
+    meta = {"malicious": [malicious, [str(m) for m in malicious]], "n_train": 2, "n_test": 2}
+    random.seed(5)
+    out_dev = io.StringIO()
+    with contextlib.redirect_stdout(out_dev):
+        auc_dev, _ = ev.entity_level_evaluation(model, "trace", cuda, metadata=meta, load_graph=lambda k, i: graphs[(k, i)])
+    # the same pipeline piece by piece: device embeddings and test set, device scores, and scikit-learn
+    # (the reference's metric functions) on those very scores
+    from sklearn.metrics import roc_auc_score
+    from magic_amd.model.metrics import entity_level_test_set
+    with torch.no_grad():
+        x_train = torch.cat([model.embed(graphs[("train", i)].to(cuda)) for i in range(2)])
+        x_test = torch.cat([model.embed(graphs[("test", i)].to(cuda)) for i in range(2)])
+    xs, ys = entity_level_test_set(x_test, malicious, 2000)
+    y = np.zeros(x_test.shape[0])
+    y[malicious] = 1.0
+    keep = [i for i in range(x_test.shape[0]) if i >= 2000 or y[i] == 1.0]          # eval.py:107-110
+    assert np.array_equal(ys.cpu().numpy(), y[keep]) and torch.equal(xs, x_test[torch.tensor(keep, device=cuda)])
+    random.seed(5)
+    m_dev, d_dev = ev.entity_level_distances(x_train, xs, 10)
+    score = (d_dev / m_dev).cpu().numpy()
+    assert abs(auc_dev - roc_auc_score(y[keep], score)) < 1e-12
+    # ... and the numpy-shaped evaluator (pinned by the reference-generated fixtures above) sees the same
+    # distances up to the float32 rounding of the standardisation
+    random.seed(5)
+    m_host, d_host = ev.entity_level_distances(x_train.cpu().numpy(), xs.cpu().numpy(), 10)
+    assert abs(float(m_dev) - m_host) < 1e-5 * m_host
+    assert np.abs(d_dev.cpu().numpy() - d_host).max() < 1e-5 * np.abs(d_host).max()
+    dev_lines = out_dev.getvalue().strip().splitlines()
+    assert [l.split(":")[0] for l in dev_lines] == ["AUC", "F1", "PRECISION", "RECALL", "TN", "FN", "TP", "FP", "#Test_AUC"]
+    counts = {l.split(":")[0]: int(l.split(":")[1]) for l in dev_lines[4:8]}
+    assert counts["TP"] + counts["FN"] == len(malicious) and sum(counts.values()) == len(keep)
