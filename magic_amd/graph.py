@@ -108,12 +108,18 @@ def build_segment_plan(ptr: torch.Tensor, light_max: int = LIGHT_MAX, chunk: int
 class Structure:
     """COO edge list plus lazily built, cached CSC/CSR arrays (shared by clones)."""
 
-    def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int):
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, checked: bool = False):
         assert src.dim() == 1 and src.shape == dst.shape
         self.src = src.to(torch.int64)
         self.dst = dst.to(torch.int64)
         self.num_nodes = int(num_nodes)
         self.num_edges = int(src.numel())
+        # node ids outside [0, N) would make the sort and every gather write / read out of bounds
+        # (dgl.graph raises for them too).  Host tensors are checked here, device tensors once, before
+        # the CSC / CSR build; ``checked`` marks endpoints that come from already checked graphs.
+        self._endpoints_ok = checked or self.num_edges == 0
+        if not self._endpoints_ok and self.src.device.type == "cpu":
+            self.check_endpoints()
         # CSC: edges sorted by destination (ties keep ascending edge id)
         self.in_ptr = self.in_src = self.in_eid = self.in_dst = None
         # CSR: edges sorted by source; out_pos = position of that edge in CSC order
@@ -124,6 +130,17 @@ class Structure:
     @property
     def device(self):
         return self.src.device
+
+    def check_endpoints(self):
+        if self._endpoints_ok:
+            return
+        lo = torch.minimum(self.src.min(), self.dst.min())
+        hi = torch.maximum(self.src.max(), self.dst.max())
+        lo, hi = (int(v) for v in torch.stack([lo, hi]).tolist())      # one read-back
+        if lo < 0 or hi >= self.num_nodes:
+            raise ValueError(f"edge endpoints must lie in [0, {self.num_nodes}): found node id "
+                             f"{lo if lo < 0 else hi}")
+        self._endpoints_ok = True
 
     def has_csr(self) -> bool:
         return self.in_ptr is not None
@@ -146,6 +163,7 @@ class Structure:
         if self.src.device.type != "cuda":
             raise RuntimeError("magic_amd: CSC/CSR construction runs on the MI355X only; "
                                "move the graph with .to('cuda') first")
+        self.check_endpoints()
         from . import ops  # noqa: F401  (registers torch.ops.magic.*)
         self.set_csr(*torch.ops.magic.csr_build(self.src, self.dst, self.num_nodes))
         return self
@@ -154,7 +172,7 @@ class Structure:
         device = torch.device(device)
         if device == self.src.device:
             return self
-        s = Structure(self.src.to(device), self.dst.to(device), self.num_nodes)
+        s = Structure(self.src.to(device), self.dst.to(device), self.num_nodes, checked=self._endpoints_ok)
         if self.has_csr():
             s.in_ptr, s.in_src, s.in_eid = (t.to(device) for t in (self.in_ptr, self.in_src, self.in_eid))
             s.out_ptr, s.out_dst, s.out_eid = (t.to(device) for t in (self.out_ptr, self.out_dst, self.out_eid))
@@ -238,7 +256,7 @@ class Graph:
         g.edata = dict(self.edata)
         g._batch_num_nodes = None if self._batch_num_nodes is None else list(self._batch_num_nodes)
         g._batch_num_edges = None if self._batch_num_edges is None else list(self._batch_num_edges)
-        g._cache = self._cache  # keyed by tensor identity, safe to share
+        g._cache = self._cache  # entries are keyed by the identity of the column tensors clones share
         g._onehot_edge = self._onehot_edge
         return g
 
@@ -252,6 +270,8 @@ class Graph:
         g.ndata = {k: v.to(device) for k, v in self.ndata.items()}
         g.edata = {k: v.to(device) for k, v in self.edata.items()}
         g._batch_num_nodes, g._batch_num_edges = self._batch_num_nodes, self._batch_num_edges
+        if self._edge_attr_marked():      # the moved attr is a copy of a tensor known to be one_hot(type)
+            g.mark_edge_attr_onehot()
         return g
 
     @contextlib.contextmanager
@@ -283,12 +303,17 @@ class Graph:
         attr = self.edata.get("attr")
         if attr is None:
             return None
-        key = ("etype", attr.data_ptr(), attr._version, tuple(attr.shape))
-        hit = self._cache.get("etype")
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        types = None
         t = self.edata.get("type")
+        # identity of the tensors the cached answer was computed from (a recycled address with the same
+        # shape must not hit): weak references to the very objects plus their version counters
+        entries = self._cache.setdefault("etype", [])
+        for (ra, va, rt, vt), res in entries:
+            if ra() is attr and va == attr._version and (rt() if rt is not None else None) is t and \
+                    (t is None or vt == t._version):
+                return res
+        key = (weakref.ref(attr), attr._version, weakref.ref(t) if t is not None else None,
+               t._version if t is not None else 0)
+        types = None
         if t is not None and t.numel() == attr.shape[0] and self._edge_attr_marked():
             types = t.view(-1).long()
         elif attr.dim() == 2 and attr.numel() > 0:
@@ -307,7 +332,7 @@ class Graph:
         if types is not None:
             s = self._s.ensure_csr()
             res = types.to(torch.int32)[s.in_eid.long()].contiguous()
-        self._cache["etype"] = (key, res)
+        entries[:] = [e for e in entries if e[0][0]() is not None][-3:] + [(key, res)]   # live tensors, newest four
         return res
 
 
@@ -393,7 +418,7 @@ def batch(graphs: Sequence[Graph]) -> Graph:
     node_off_per_edge64 = offs.vec(n_off[:-1], e_cnt, torch.int64)
     src = cat("src") + node_off_per_edge64
     dst = cat("dst") + node_off_per_edge64
-    s = Structure(src, dst, n_off[-1])
+    s = Structure(src, dst, n_off[-1], checked=all(g._s._endpoints_ok for g in graphs))
     if all(g._s.has_csr() for g in graphs):
         # no device synchronisation below: every size is already known on the host
         i32 = torch.int32

@@ -47,18 +47,37 @@ def _sorted_edge_keys(g: Graph) -> torch.Tensor:
     return keys
 
 
+def negative_candidate_count(num_samples: int) -> int:
+    """Candidates drawn for ``num_samples`` negative pairs: a quarter more, as DGL's sampler oversamples
+    (its ``redundancy``) so that rejected and repeated draws rarely leave it short."""
+    return num_samples + (num_samples + 3) // 4
+
+
 def _negative_candidates(g: Graph, num_samples: int, generator: torch.Generator = None):
-    """``num_samples`` uniformly drawn (src, dst) pairs and the mask of those that are neither edges
-    of ``g`` nor self-loops (fixed shapes: nothing is read back to the host)."""
+    """Candidate (src, dst) pairs for ``dgl.sampling.global_uniform_negative_sampling(g, num_samples)``
+    (``model/autoencoder.py:251``) with fixed shapes, so that nothing is read back to the host:
+    ``negative_candidate_count(num_samples)`` uniformly drawn pairs and a mask that accepts, in draw
+    order, the first ``num_samples`` of them that are no edge of ``g``, no self-loop and no repeat of an
+    earlier accepted pair (DGL samples without replacement)."""
     n = g.num_nodes()
     dev = g.device
-    u = torch.randint(0, n, (num_samples,), device=dev, generator=generator)
-    v = torch.randint(0, n, (num_samples,), device=dev, generator=generator)
+    m = negative_candidate_count(num_samples)
+    u = torch.randint(0, n, (m,), device=dev, generator=generator)
+    v = torch.randint(0, n, (m,), device=dev, generator=generator)
     ekey = _sorted_edge_keys(g)
     key = u * n + v
     pos = torch.searchsorted(ekey, key).clamp_(max=max(ekey.numel() - 1, 0))
     is_edge = (ekey[pos] == key) if ekey.numel() else torch.zeros_like(key, dtype=torch.bool)
-    return u, v, (u != v) & ~is_edge
+    ok = (u != v) & ~is_edge
+    # repeats: stable sort by key, every element but the first of a run of equal keys is a repeat
+    skey, order = torch.sort(key, stable=True)
+    repeat_sorted = torch.zeros(m, dtype=torch.bool, device=dev)
+    repeat_sorted[1:] = skey[1:] == skey[:-1]
+    repeat = torch.empty_like(repeat_sorted)
+    repeat[order] = repeat_sorted
+    ok &= ~repeat
+    ok &= torch.cumsum(ok, 0) <= num_samples
+    return u, v, ok
 
 
 def global_uniform_negative_sampling(g: Graph, num_samples: int, generator: torch.Generator = None):

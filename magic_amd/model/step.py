@@ -82,9 +82,11 @@ class CapturedTrainStep:
         self.pos = torch.zeros(self.thr, dtype=torch.int64, device=dev)
         self.n_masks = len(model.encoder.gats) + 1
         self.seeds = torch.zeros(self.n_masks, dtype=torch.int64, device=dev)
-        self.neg_u = torch.zeros(self.thr, dtype=torch.int64, device=dev)   # candidate negative pairs
-        self.neg_v = torch.zeros(self.thr, dtype=torch.int64, device=dev)
-        self.neg_ok = torch.zeros(self.thr, dtype=torch.bool, device=dev)   # ... and which of them count
+        from .autoencoder import negative_candidate_count
+        self.n_neg = negative_candidate_count(self.thr)
+        self.neg_u = torch.zeros(self.n_neg, dtype=torch.int64, device=dev)   # candidate negative pairs
+        self.neg_v = torch.zeros(self.n_neg, dtype=torch.int64, device=dev)
+        self.neg_ok = torch.zeros(self.n_neg, dtype=torch.bool, device=dev)   # ... and which of them count
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self._graphs = None
         self._capture = capture
@@ -164,7 +166,7 @@ class CapturedTrainStep:
         generator with ``mask_rng='device'``), ``random.sample(range(E), T)``, T uniformly drawn
         candidate pairs of which the non-edges that are no self-loops count (the stand-in for DGL's
         negative sampler, drawn from torch's device generator), dropout seeds from torch's CPU
-        generator.  ``neg_pairs`` must hold exactly T = min(10000, N) pairs."""
+        generator.  ``neg_pairs`` may hold up to ``negative_candidate_count(T)`` pairs, T = min(10000, N)."""
         from .autoencoder import _negative_candidates
         dev = self.g.device
         if perm is None:
@@ -181,9 +183,13 @@ class CapturedTrainStep:
         else:
             u, v = (torch.as_tensor(t).long().to(dev) for t in neg_pairs)
             ok = torch.ones_like(u, dtype=torch.bool) if neg_valid is None else torch.as_tensor(neg_valid).to(dev)
-        self.neg_u.copy_(u)
-        self.neg_v.copy_(v)
-        self.neg_ok.copy_(ok)
+            if u.numel() > self.n_neg:
+                raise ValueError(f"at most {self.n_neg} candidate negative pairs fit the recorded step")
+        k = u.numel()                       # fewer injected pairs than slots: the rest does not count
+        self.neg_ok.zero_()
+        self.neg_u[:k].copy_(u)
+        self.neg_v[:k].copy_(v)
+        self.neg_ok[:k].copy_(ok)
 
     def __call__(self, **inputs) -> torch.Tensor:
         """Run exactly one training step; returns the (scaled) loss as a device scalar that the next

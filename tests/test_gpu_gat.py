@@ -387,3 +387,59 @@ def test_custom_operators_called_directly(cuda):
     lo.backward()
     assert abs(float(loss) - float(lo)) < 1e-5 and rel_err(xs.grad, xo.grad) < 1e-4
     assert magic_amd.__version__
+
+
+def test_negative_candidates_are_distinct_non_edges_without_self_loops(cuda):
+    """The stand-in for dgl.sampling.global_uniform_negative_sampling (model/autoencoder.py:251) on a
+    small dense graph, where rejections and repeats are frequent: the accepted pairs are distinct, no
+    edges, no self-loops, at most k, and k exactly whenever enough candidates survive."""
+    from magic_amd.graph import Graph
+    from magic_amd.model.autoencoder import _negative_candidates, negative_candidate_count
+    n = 40
+    rng = np.random.default_rng(0)
+    dense = rng.random((n, n)) < 0.3
+    src, dst = np.nonzero(dense)
+    g = Graph(torch.from_numpy(src), torch.from_numpy(dst), n).to(cuda)
+    edges = set(zip(src.tolist(), dst.tolist()))
+    k = 300
+    gen = torch.Generator(device=cuda).manual_seed(1)
+    u, v, ok = _negative_candidates(g, k, generator=gen)
+    assert u.shape == v.shape == ok.shape == (negative_candidate_count(k),)
+    pairs = list(zip(u[ok].tolist(), v[ok].tolist()))
+    assert 0 < len(pairs) <= k and len(set(pairs)) == len(pairs)
+    assert all(a != b and (a, b) not in edges for a, b in pairs)
+    # every rejected candidate before the last accepted one is an edge, a self-loop or a repeat
+    last = int(torch.nonzero(ok)[-1])
+    seen = set()
+    for j in range(last + 1):
+        p = (int(u[j]), int(v[j]))
+        good = p[0] != p[1] and p not in edges and p not in seen
+        assert bool(ok[j]) == good
+        seen.add(p)
+    u2, v2, ok2 = _negative_candidates(g, 5, generator=gen)
+    assert int(ok2.sum()) == 5          # plenty of candidates: exactly k are accepted
+
+
+def test_edge_type_cache_follows_tensor_identity_and_endpoints_are_checked(cuda):
+    from magic_amd.graph import Graph
+    n_dim, e_dim = 5, 7
+    src, dst, nt, et = small_graph(120, 500, n_dim, e_dim, seed=2)
+    g = to_graph(src, dst, 120, nt, et, n_dim, e_dim, cuda)
+    first = g.edge_types_csc().clone()
+    c = g.clone()
+    # a new attribute tensor of the same shape (possibly at a recycled address) with other types
+    new_types = (g.edata["type"] + 1) % e_dim
+    c.edata["type"] = new_types
+    c.edata["attr"] = torch.nn.functional.one_hot(new_types, e_dim).float()
+    got = c.edge_types_csc()
+    assert torch.equal(got, new_types.to(torch.int32)[g.structure.in_eid.long()])
+    assert torch.equal(g.edge_types_csc(), first)                    # the original graph keeps its own answer
+    moved = g.to("cpu")
+    assert not moved._edge_attr_marked()                             # to_graph builds attr without the mark ...
+    from magic_amd.utils.loaddata import transform_graph
+    assert transform_graph(moved, n_dim, e_dim).to(cuda)._edge_attr_marked()   # ... transform_graph's mark survives .to()
+    with pytest.raises(ValueError):
+        Graph(torch.tensor([0, 5]), torch.tensor([1, 2]), 5)          # host endpoints: checked at construction
+    bad = Graph(torch.tensor([0, 1], device=cuda), torch.tensor([1, -1], device=cuda), 5)
+    with pytest.raises(ValueError):
+        bad.structure.ensure_csr()                                    # device endpoints: checked before the sort
