@@ -163,14 +163,17 @@ __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
     }
     __syncthreads();
 
-    for (int64_t t0 = t_lo; t0 < t_hi; t0 += TT) {
-        // stage TT train rows (zero padded) + their squared norms
-        __syncthreads();
+    // Software pipeline over the train tiles: the global loads of tile i+1 are issued into registers
+    // before the matrix work on tile i and written to LDS after it, so their latency hides behind the
+    // MFMAs instead of standing between two barriers.
+    float4 pre[TT / 16];
+    double pre_tn = (double)INFINITY;
+    auto fetch = [&](int64_t t0) {
 #pragma unroll
         for (int i = 0; i < TT / 16; ++i) {
-            int r = (tid >> 4) + 16 * i;
-            int c4 = (tid & 15) * 4;
-            int64_t row = t0 + r;
+            const int r = (tid >> 4) + 16 * i;
+            const int c4 = (tid & 15) * 4;
+            const int64_t row = t0 + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < t_hi) {
                 const float *p = a.train + row * a.ld_train + c4;
@@ -182,10 +185,20 @@ __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
                     if (c4 + 2 < a.d) v.z = p[2];
                 }
             }
-            *reinterpret_cast<float4 *>(tile + r * LDT + c4) = v;
+            pre[i] = v;
         }
-        if (tid < TT) tn[tid] = (t0 + tid < t_hi) ? a.tnorm[t0 + tid] : (double)INFINITY;
+        if (tid < TT) pre_tn = (t0 + tid < t_hi) ? a.tnorm[t0 + tid] : (double)INFINITY;
+    };
+    if (t_lo < t_hi) fetch(t_lo);
+    for (int64_t t0 = t_lo; t0 < t_hi; t0 += TT) {
+        // stage the prefetched TT train rows (zero padded) + their squared norms
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TT / 16; ++i)
+            *reinterpret_cast<float4 *>(tile + ((tid >> 4) + 16 * i) * LDT + (tid & 15) * 4) = pre[i];
+        if (tid < TT) tn[tid] = pre_tn;
+        __syncthreads();
+        if (t0 + TT < t_hi) fetch(t0 + TT);
 
 #pragma unroll 1
         for (int tb = 0; tb < TT / 16; ++tb) {
