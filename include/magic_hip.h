@@ -161,8 +161,12 @@ int magic_proj_bwd_weight(int64_t n_rows, int32_t m, int32_t f,
  * H*D must be one of the compiled shapes (D in {4,8,16,32,64}, H*D/4 a power of two
  * <= 64); callers zero-pad narrower heads.
  * Outputs: out [N,H*D]; pre [N,H*D] (optional, needed by backward when prelu_w is given);
- * attn [E,H] in CSC order with the SIGN BIT set where the pre-activation logit was
- * negative (|attn| is the attention weight; backward needs the sign for leaky_relu').
+ * attn [E,H] (optional; the second result of GATConv.forward(get_attention=True),
+ * model/gat.py:337-338) in CSC order with the SIGN BIT set where the pre-activation logit was
+ * negative (|attn| is the attention weight);
+ * stat [N,H,2] (optional, what magic_gat_bwd needs): per destination and head the pair
+ * (et[v,h], max + log sum exp of the leaky-ReLU logits of v's in-edges), from which backward
+ * recomputes a[e,h] = exp(leaky_relu(logit) - stat[v,h,1]).  Nodes without in-edges get (et, 0).
  * ---------------------------------------------------------------------------------- */
 size_t magic_gat_fwd_workspace_bytes(int32_t n_edges, int32_t n_chunks, int32_t n_heads, int32_t head_dim);
 int magic_gat_fwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t head_dim,
@@ -174,7 +178,7 @@ int magic_gat_fwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t hea
                   float negative_slope, const float *bias, const float *res, int64_t ld_res,
                   const uint8_t *res_mask /* [N,H*D] dropout keep mask of res, or NULL */, float res_scale,
                   const float *prelu_w,
-                  float *out, int64_t ld_out, float *pre, float *attn,
+                  float *out, int64_t ld_out, float *pre, float *attn, float *stat,
                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
@@ -228,27 +232,31 @@ int magic_fold_bwd(int32_t n_heads, int32_t head_dim, int32_t head_dim_padded, i
 /* ------------------------------------------------------------------------------------
  * Backward of magic_gat_fwd (DGL's EdgeSoftmax / GSpMM / GSDDMM backward + the PReLU,
  * bias and residual adjoints that torch autograd runs for model/gat.py:302-335).
- * Inputs: the forward's hs, attn, pre; d_out [N,H*D].
+ * Inputs: the forward's hs, eh (the node's score as a source, row stride ld_score), stat, pre and
+ * its edge term (ee_table + etype_csr[E] = edge types in CSR order, or the dense ee_csc[E,H] in
+ * CSC order); d_out [N,H*D].  in_pos[E] = CSR position of every CSC edge, out_pos[E] = CSC
+ * position of every CSR edge (inverse permutations of each other).
  * Outputs:
  *   d_pre  [N,ld_dpre] gradient w.r.t. the pre-activation (= gradient of the residual input)
  *   d_y    [N,ld_dy] cols [0,C) d_hs, [C,C+H) d_eh, [C+H,C+2H) d_et  (C = H*D)
- *   d_ee_table [e_dim,H] (when etype_csc != NULL)   -- fixed-order reduction, no atomics
- *   d_logit [E,H]   CSC order: gradient w.r.t. the attention logit of every edge and head
- *                    (= gradient w.r.t. ee[e,:] on the dense-ee path)
- * The sweep gathers one node row per edge: in source (CSR) order it reads d_pre[dst] once and
- * uses it for d_hs[src] += a d_pre[dst] and for the SDDMM term <hs[src], d_pre[dst]>; the
- * softmax backward then only streams [E,H] arrays.  in_src is not read (kept for symmetry
- * with magic_gat_fwd).  d_pre may alias d_out when prelu_w is NULL (no copy is made).
+ *   d_ee_table [e_dim,H] (with ee_table)   -- fixed-order reduction, no atomics
+ *   d_logit [E,H]   optional, CSC order: gradient w.r.t. the attention logit of every edge and
+ *                    head (= gradient w.r.t. ee[e,:] on the dense-ee path)
  *   d_bias [H*D] (optional), d_prelu_w [1] (optional)
+ * The source (CSR) sweep gathers one node row per edge, d_pre[dst], and uses it for
+ * d_hs[src] += a d_pre[dst] and for t = <hs[src], d_pre[dst]>; a is recomputed from eh[src],
+ * the edge term and stat[dst].  The (a, t) pairs cross to destination order once (through
+ * in_pos) for delta[v] = sum a t and d_et; d_logit = a (t - delta[dst]) leaky' and d_eh are
+ * formed in source order again.  d_pre may alias d_out when prelu_w is NULL (no copy is made).
  * ---------------------------------------------------------------------------------- */
 size_t magic_gat_bwd_workspace_bytes(int32_t n_nodes, int32_t n_edges, int32_t n_chunks_in,
                                      int32_t n_chunks_out, int32_t n_heads, int32_t head_dim,
                                      int32_t e_dim);
 int magic_gat_bwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t head_dim,
-                  const magic_plan *in_plan, const int32_t *in_src,
+                  const magic_plan *in_plan, const int32_t *in_pos,
                   const magic_plan *out_plan, const int32_t *out_dst, const int32_t *out_pos,
-                  const float *hs, int64_t ld_hs, const float *attn,
-                  const int32_t *etype_csc, int32_t e_dim,
+                  const float *hs, int64_t ld_hs, const float *eh, int64_t ld_score, const float *stat,
+                  const float *ee_table, const int32_t *etype_csr, const float *ee_csc, int32_t e_dim,
                   float negative_slope, const float *pre,
                   const float *act_out, int64_t ld_act /* forward output, used when *prelu_w > 0 */,
                   const float *prelu_w,

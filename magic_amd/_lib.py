@@ -52,11 +52,11 @@ SYMBOLS = {
     "magic_gat_fwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "magic_gat_fwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, c_vp,
                               c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp,
-                              c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
+                              c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_gat_bwd_workspace_bytes": (c_sz, [c_i32] * 7),
     "magic_gat_bwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, C.POINTER(MagicPlan), c_vp,
-                              c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64,
-                              c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+                              c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_i64,
+                              c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_sce_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "magic_sce_fwd_bwd": (c_i32, [c_i64, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32,
                                   c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -358,10 +358,11 @@ def fold_bwd(H: int, D: int, Dp: int, w_fc, attn_h, attn_t, w_efc, attn_e, d_w_a
 # ------------------------------------------------------------------------------------- GAT
 def gat_fwd(struct, H: int, D: int, hs, eh, et, ee_table, etype_csc, ee_csc, slope: float, bias, res,
             prelu_w, want_pre: bool, res_mask: Optional[torch.Tensor] = None, res_scale: float = 1.0,
-            out: Optional[torch.Tensor] = None):
+            out: Optional[torch.Tensor] = None, want_attn: bool = True, want_stat: bool = False):
     """``out`` may be a preallocated [N,C] view (unit inner stride, 16-byte aligned rows), e.g. a column
     block of the concatenated hidden-state buffer.  ``pre`` is only written by the kernel when the
-    PReLU slope is <= 0 (otherwise backward recovers it from ``out``)."""
+    PReLU slope is <= 0 (otherwise backward recovers it from ``out``).  Returns
+    (out, pre | None, attn [E,H] | None, stat [N,H,2] | None); ``stat`` is what ``gat_bwd`` needs."""
     lib = load()
     from .graph import LIGHT_MAX
     N, E = struct.num_nodes, struct.num_edges
@@ -371,11 +372,13 @@ def gat_fwd(struct, H: int, D: int, hs, eh, et, ee_table, etype_csc, ee_csc, slo
         out = torch.empty(N, Cc, dtype=torch.float32, device=dev)
     assert out.shape == (N, Cc) and out.stride(1) == 1
     pre = torch.empty(N, Cc, dtype=torch.float32, device=dev) if want_pre else None
-    attn = torch.empty(E, H, dtype=torch.float32, device=dev)
+    attn = torch.empty(E, H, dtype=torch.float32, device=dev) if want_attn else None
+    stat = torch.empty(N, H, 2, dtype=torch.float32, device=dev) if want_stat else None
     plan = make_plan(struct.plan_in, LIGHT_MAX)
     nbytes = lib.magic_gat_fwd_workspace_bytes(E, struct.plan_in.n_chunks, H, D)
     ws = workspace(nbytes, dev)
     res = _rows(res)
+    assert eh.stride(0) == et.stride(0)
     if res_mask is not None:
         assert res_mask.dtype == torch.uint8 and res_mask.shape == (N, Cc) and res_mask.is_contiguous()
     _check(lib.magic_gat_fwd(N, E, H, D, C.byref(plan), _dev(struct.in_src), _dev(struct.in_dst),
@@ -383,22 +386,24 @@ def gat_fwd(struct, H: int, D: int, hs, eh, et, ee_table, etype_csc, ee_csc, slo
                              _dev(et, torch.float32, "et"), eh.stride(0), _dev(ee_table), _dev(etype_csc), _dev(ee_csc),
                              float(slope), _dev(bias), _dev(res), res.stride(0) if res is not None else 0,
                              _dev(res_mask), float(res_scale), _dev(prelu_w), _dev(out), out.stride(0), _dev(pre),
-                             _dev(attn), ws.data_ptr(), ws.numel(), _stream()), "magic_gat_fwd")
-    return out, pre, attn
+                             _dev(attn), _dev(stat), ws.data_ptr(), ws.numel(), _stream()), "magic_gat_fwd")
+    return out, pre, attn, stat
 
 
-def gat_bwd(struct, H: int, D: int, hs, attn, etype_csc, e_dim: int, slope: float, pre, act_out, prelu_w, d_out,
-            d_pre, d_y, want_bias: bool):
+def gat_bwd(struct, H: int, D: int, hs, eh, stat, ee_table, etype_csr, ee_csc, e_dim: int, slope: float, pre,
+            act_out, prelu_w, d_out, d_pre, d_y, want_bias: bool, want_dlogit: bool = False):
     """Fills d_pre [N,>=C] and d_y [N,>=C+2H] (views allowed, unit inner stride); with
     ``prelu_w is None`` ``d_pre`` may be the very tensor passed as ``d_out`` (no copy is made).
-    Returns (d_ee_table | None, d_logit [E,H] in CSC order, d_bias | None, d_prelu_w | None)."""
+    ``eh`` [N,H] (row stride allowed), ``stat`` [N,H,2] from ``gat_fwd(want_stat=True)``; the edge term
+    as in forward, with the edge types in CSR order.
+    Returns (d_ee_table | None, d_logit [E,H] in CSC order | None, d_bias | None, d_prelu_w | None)."""
     lib = load()
     from .graph import LIGHT_MAX
     N, E = struct.num_nodes, struct.num_edges
     dev = hs.device
     Cc = H * D
-    rec = torch.empty(E, H, dtype=torch.float32, device=dev)   # d_logit per edge and head, CSC order
-    d_table = torch.empty(e_dim, H, dtype=torch.float32, device=dev) if etype_csc is not None else None
+    rec = torch.empty(E, H, dtype=torch.float32, device=dev) if want_dlogit else None
+    d_table = torch.empty(e_dim, H, dtype=torch.float32, device=dev) if ee_table is not None else None
     d_bias = torch.empty(Cc, dtype=torch.float32, device=dev) if want_bias else None
     d_prelu = torch.empty(1, dtype=torch.float32, device=dev) if prelu_w is not None else None
     pin = make_plan(struct.plan_in, LIGHT_MAX)
@@ -408,9 +413,11 @@ def gat_bwd(struct, H: int, D: int, hs, attn, etype_csc, e_dim: int, slope: floa
     ws = workspace(nbytes, dev)
     d_out = _rows(d_out)
     act_out = _rows(act_out)
-    _check(lib.magic_gat_bwd(N, E, H, D, C.byref(pin), _dev(struct.in_src), C.byref(pout), _dev(struct.out_dst),
+    assert stat.shape == (N, H, 2) and stat.is_contiguous() and eh.stride(-1) == 1
+    _check(lib.magic_gat_bwd(N, E, H, D, C.byref(pin), _dev(struct.in_pos), C.byref(pout), _dev(struct.out_dst),
                              _dev(struct.out_pos), _dev(hs, torch.float32, "hs"), hs.stride(0),
-                             _dev(attn, torch.float32, "attn"), _dev(etype_csc), int(e_dim), float(slope),
+                             _dev(eh, torch.float32, "eh"), eh.stride(0), _dev(stat, torch.float32, "stat"),
+                             _dev(ee_table), _dev(etype_csr), _dev(ee_csc), int(e_dim), float(slope),
                              _dev(pre), _dev(act_out), act_out.stride(0) if act_out is not None else 0,
                              _dev(prelu_w), _dev(d_out, torch.float32, "d_out"), d_out.stride(0),
                              _dev(d_pre), d_pre.stride(0), _dev(d_y), d_y.stride(0), _dev(d_table), _dev(rec),

@@ -1,13 +1,22 @@
-// GAT layer, edge phase, backward.  Segmented sweeps, no atomics, one gather of node rows:
+// GAT layer, edge phase, backward.  Segmented sweeps, no atomics, one gather of node rows and one
+// transposition of per-edge data between source order (CSR) and destination order (CSC):
 //   node adjoint      PReLU / bias adjoints of the incoming gradient (skipped when the caller
 //                     already holds the pre-activation gradient);
 //   source sweep      (CSR) per edge u->v gathers d_pre[v] once and uses it twice:
 //                     d_hs[u] += a_e d_pre[v]   and   t_e = <hs[u], d_pre[v]> per head
-//                     (hs[u] is the sweep's own row), t_e stored at the edge's CSC position;
-//   destination pass  (CSC, streams [E,H] arrays only) softmax backward
-//                     d_logit_e = a_e (t_e - sum_seg a t) * leaky', d_et[v] = sum_seg d_logit;
-//   source pass 2     d_eh[u] = sum over out-edges of d_logit (16-byte gathers);
-//   then a fixed-order reduction of d_logit per edge type for the edge-score table.
+//                     (hs[u] is the sweep's own row).  The attention weight is recomputed, not
+//                     fetched: a_e = exp(leaky(eh[u] + ee_e + et[v]) - lse[v]) with (et[v], lse[v])
+//                     from the forward's per-destination table [N,H,2] (small, hubs stay cached)
+//                     and ee_e from the edge-type table in LDS.  (a_e, t_e) pairs leave in CSR
+//                     order as streaming stores;
+//   destination pass  (CSC) per destination v gathers the pairs of its in-edges through in_pos
+//                     (the one random [E,H] access of the whole backward), once: delta_v = sum a_e t_e
+//                     and d_et[v] = sum a_e (t_e - delta_v) leaky'_e from three segment sums;
+//                     stores delta_v;
+//   source pass 2     (CSR) streams the pairs: d_logit_e = a_e (t_e - delta[dst e]) leaky'_e with
+//                     delta from the per-node table, d_eh[u] = sum over out-edges; d_logit leaves
+//                     in CSR order (and is scattered to CSC order only when the caller wants it);
+//   edge-type table   fixed-order reduction of d_logit per edge type (CSR order).
 #include "gat_common.h"
 
 namespace magic {
@@ -17,11 +26,16 @@ struct BwdArgs {
     PlanDev pin;   // CSC plan
     PlanDev pout;  // CSR plan
     const int32_t *out_dst;
-    const int32_t *out_pos;
+    const int32_t *out_pos;  // [E] CSC position of every CSR edge
+    const int32_t *in_pos;   // [E] CSR position of every CSC edge
     const float *hs;
     int64_t ld_hs;
-    const float *attn;  // [E,H] packed (sign bit = logit not positive), CSC order
-    const int32_t *etype;
+    const float *eh;  // [N,ld_s] head scores of the node as a source
+    int64_t ld_s;
+    const float *stat;      // [N,H,2] (et, log-sum-exp of the in-edge logits) per destination and head
+    const float *ee_table;  // [e_dim,H] or null
+    const int32_t *etype;   // [E] edge type, CSR order (with ee_table)
+    const float *ee;        // [E,H] dense edge term, CSC order (without ee_table)
     int e_dim;
     float slope;
     const float *pre;      // [N,C] pre-activation (valid when the slope is <= 0)
@@ -35,16 +49,18 @@ struct BwdArgs {
     float *d_y;
     int64_t ld_dy;
     float *d_table;  // [e_dim,H]
-    float *dl;       // [E,H] d_logit, CSC order
+    float *dl;       // [E,H] d_logit, CSC order, or null when the caller does not need it
     float *d_bias;   // [C]
     float *d_prelu;  // [1]
     // workspace
-    float *t;         // [E,H] <hs[src], d_pre[dst]> per head, CSC order
+    float *pairs;     // [E,H,2] (attention weight with the leaky-ReLU sign, <hs[src], d_pre[dst]>), CSR order
+    float *dl_csr;    // [E,H] d_logit, CSR order
+    float *delta;     // [N,H] sum over in-edges of a * t
     float *ws_bias;   // [grid_light, C]
     float *ws_prelu;  // [grid_light]
     int grid_light;
     float *ws_delta;  // [n_chunks_in, H]
-    float *ws_det;    // [n_chunks_in, H]
+    float *ws_det;    // [n_chunks_in, H, 2]
     float *ws_acc;    // [n_chunks_out, C]
     float *ws_deh;    // [n_chunks_out, H]
     float *ws_table;  // [grid_table, e_dim*H]
@@ -130,53 +146,134 @@ __global__ __launch_bounds__(256) void k_bwd_reduce_bias(BwdArgs a, int C) {
 }
 
 // ---- source sweep --------------------------------------------------------------------------
+constexpr int MAX_E_DIM = 32;
+
+// edge-type table into LDS (every thread of the block calls this once, before any early exit)
+template <int H, bool TABLE> __device__ __forceinline__ void stage_table(const BwdArgs &a, float *tbl) {
+    if (TABLE) {
+        for (int i = threadIdx.x; i < a.e_dim * H; i += blockDim.x) tbl[i] = a.ee_table[i];
+        __syncthreads();
+    }
+}
+
+// edge term of CSR edge j, head h
+template <int H, bool TABLE>
+__device__ __forceinline__ float edge_term(const BwdArgs &a, const float *tbl, int j, int h) {
+    return TABLE ? tbl[a.etype[j] * H + h] : a.ee[(int64_t)a.out_pos[j] * H + h];
+}
+
 // One lane group per source node u with <= light_max out-edges.  Per edge: the destination's
-// gradient row is gathered once; a_e comes from the edge's CSC slot, t_e goes back to it.
-template <int H, int LPH>
+// gradient row and its (et, lse) pair are gathered once; the pair (a_e, t_e) is streamed out.
+//
+// The walk is software-pipelined so that one batch of SB edges costs one memory round trip instead
+// of the chain walk order -> segment bounds -> destination ids -> rows: while the rows of the current
+// batch are in flight, the destination ids / edge types of the NEXT batch (of this node or of the next
+// node), the next node's own row, the segment bounds of the node after it and the walk-order entry of
+// the one after that are requested as well.  Every address of an iteration is known when it starts.
+// All loads are unconditional (clamped indices); only stores and accumulations are predicated.
+template <int H, int LPH, bool TABLE>
 __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
     constexpr int G = H * LPH;
     constexpr int NPB = 256 / G;
-    constexpr int SB = 4;  // edges per batch (8 measured the same: the sweep is bandwidth-bound)
+    constexpr int SB = 4;  // edges per batch
+    __shared__ float tbl[TABLE ? MAX_E_DIM * H : 1];
+    stage_table<H, TABLE>(a, tbl);
     const int g = threadIdx.x % G;
     const int h = g / LPH;
     const bool writer = (g % LPH) == 0;
     const int slot = threadIdx.x / G;
-    for (int ui = blockIdx.x * NPB + slot; ui < a.N; ui += gridDim.x * NPB) {
-        const int u = (G >= 8 && a.pout.order) ? a.pout.order[ui] : ui;
-        const int b = a.pout.ptr[u], e = a.pout.ptr[u + 1];
-        if (e - b > a.pout.light_max) continue;
-        const float4 hu = ld4_nt(a.hs + (int64_t)u * a.ld_hs + g * 4);
-        float4 acc = f4zero();
-        for (int j = b; j < e; j += SB) {  // batches with clamped indices: loads stay unconditional
-            int pos[SB];
-            float4 r[SB];
-            float w[SB];
+    const int stride = gridDim.x * NPB;
+    const bool ordered = G >= 8 && a.pout.order != nullptr;
+    const int last_node = a.N - 1;
+    int i0 = blockIdx.x * NPB + slot;  // walk index of the current node
+    auto node_at = [&](int i) {
+        i = min(i, last_node);
+        return ordered ? a.pout.order[i] : i;
+    };
+    // edge slot of batch element k (clamped into the segment; into the edge array for empty segments)
+    auto slot_of = [&](int j, int e, int k) { return max(min(j + k, e - 1), 0); };
+    // ---- pipeline fill
+    int u0 = node_at(i0), u1 = node_at(i0 + stride), u2 = node_at(i0 + 2 * stride);
+    int b0 = a.pout.ptr[u0], e0 = a.pout.ptr[u0 + 1];
+    int b1 = a.pout.ptr[u1], e1 = a.pout.ptr[u1 + 1];
+    int j = b0;
+    int v[SB], jj[SB];
+    float ee[SB];
 #pragma unroll
-            for (int k = 0; k < SB; ++k) {
-                const int jj = min(j + k, e - 1);
-                pos[k] = a.out_pos[jj];
-                r[k] = ld4(a.d_pre + (int64_t)a.out_dst[jj] * a.ld_dpre + g * 4);
-            }
+    for (int k = 0; k < SB; ++k) {
+        jj[k] = slot_of(j, e0, k);
+        v[k] = a.out_dst[jj[k]];
+        ee[k] = edge_term<H, TABLE>(a, tbl, jj[k], h);
+    }
+    float4 hu = ld4_nt(a.hs + (int64_t)u0 * a.ld_hs + g * 4);
+    float ehu = a.eh[(int64_t)u0 * a.ld_s + h];
+    float4 acc = f4zero();
+    while (i0 < a.N) {
+        const bool light = e0 - b0 <= a.pout.light_max;
+        const bool last = !light || j + SB >= e0;  // this batch ends the node
+        // 1. gathers of the current batch
+        float4 r[SB];
+        float2 st[SB];
 #pragma unroll
-            for (int k = 0; k < SB; ++k) w[k] = fabsf(a.attn[(int64_t)pos[k] * H + h]);
+        for (int k = 0; k < SB; ++k) {
+            r[k] = ld4(a.d_pre + (int64_t)v[k] * a.ld_dpre + g * 4);
+            st[k] = *reinterpret_cast<const float2 *>(a.stat + ((int64_t)v[k] * H + h) * 2);
+        }
+        // 2. requests for what the following iterations need
+        const int nj = last ? b1 : j + SB, ne = last ? e1 : e0;
+        int nv[SB], njj[SB];
+        float nee[SB];
 #pragma unroll
-            for (int k = 0; k < SB; ++k) {
-                const float tt = head_sum<LPH>(dot4(r[k], hu));
-                if (j + k < e) {
-                    if (writer) a.t[(int64_t)pos[k] * H + h] = tt;
-                    fma4(acc, w[k], r[k]);
-                }
+        for (int k = 0; k < SB; ++k) {
+            njj[k] = slot_of(nj, ne, k);
+            nv[k] = a.out_dst[njj[k]];
+            nee[k] = edge_term<H, TABLE>(a, tbl, njj[k], h);
+        }
+        float4 nhu = hu;
+        float nehu = ehu;
+        int b2 = 0, e2 = 0, u3 = 0;
+        if (last) {
+            nhu = ld4_nt(a.hs + (int64_t)u1 * a.ld_hs + g * 4);
+            nehu = a.eh[(int64_t)u1 * a.ld_s + h];
+            b2 = a.pout.ptr[u2], e2 = a.pout.ptr[u2 + 1];
+            u3 = node_at(i0 + 3 * stride);
+        }
+        // 3. the batch itself
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+            const float x = (ehu + ee[k]) + st[k].x;
+            const float w = __expf(leaky(x, a.slope) - st[k].y);
+            const float tt = head_sum<LPH>(dot4(r[k], hu));
+            if (light && j + k < e0) {
+                if (writer) st2_nt(a.pairs + ((int64_t)(j + k) * H + h) * 2, pack_attn(w, x), tt);
+                fma4(acc, w, r[k]);
             }
         }
-        st4_nt(a.d_y + (int64_t)u * a.ld_dy + g * 4, acc);
+        // 4. advance
+        if (last) {
+            if (light) st4_nt(a.d_y + (int64_t)u0 * a.ld_dy + g * 4, acc);
+            acc = f4zero();
+            u0 = u1, b0 = b1, e0 = e1;
+            u1 = u2, b1 = b2, e1 = e2;
+            u2 = u3;
+            hu = nhu, ehu = nehu;
+            i0 += stride;
+            j = b0;
+        } else {
+            j += SB;
+        }
+#pragma unroll
+        for (int k = 0; k < SB; ++k) v[k] = nv[k], ee[k] = nee[k];
     }
 }
 
-template <int H, int LPH>
+template <int H, int LPH, bool TABLE>
 __global__ __launch_bounds__(256) void k_bwd_src_heavy1(BwdArgs a) {
     constexpr int G = H * LPH;
     constexpr int NSG = 64 / G;
     constexpr int C = G * 4;
+    __shared__ float tbl[TABLE ? MAX_E_DIM * H : 1];
+    stage_table<H, TABLE>(a, tbl);
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= a.pout.n_chunks) return;
@@ -185,25 +282,28 @@ __global__ __launch_bounds__(256) void k_bwd_src_heavy1(BwdArgs a) {
     const int g = lane % G, sg = lane / G, h = g / LPH;
     const bool writer = (g % LPH) == 0;
     const float4 hu = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
+    const float ehu = a.eh[(int64_t)u * a.ld_s + h];
     float4 acc = f4zero();
     for (int j = beg + sg; j < end; j += 4 * NSG) {
-        int pos[4];
         float4 r[4];
-        float w[4];
+        float2 st[4];
+        float ee[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int jj = min(j + k * NSG, end - 1);
-            pos[k] = a.out_pos[jj];
-            r[k] = ld4(a.d_pre + (int64_t)a.out_dst[jj] * a.ld_dpre + g * 4);
+            const int v = a.out_dst[jj];
+            r[k] = ld4(a.d_pre + (int64_t)v * a.ld_dpre + g * 4);
+            st[k] = *reinterpret_cast<const float2 *>(a.stat + ((int64_t)v * H + h) * 2);
+            ee[k] = edge_term<H, TABLE>(a, tbl, jj, h);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = fabsf(a.attn[(int64_t)pos[k] * H + h]);
-#pragma unroll
         for (int k = 0; k < 4; ++k) {
+            const float x = (ehu + ee[k]) + st[k].x;
+            const float w = __expf(leaky(x, a.slope) - st[k].y);
             const float tt = head_sum<LPH>(dot4(r[k], hu));
             if (j + k * NSG < end) {
-                if (writer) a.t[(int64_t)pos[k] * H + h] = tt;
-                fma4(acc, w[k], r[k]);
+                if (writer) st2_nt(a.pairs + ((int64_t)(j + k * NSG) * H + h) * 2, pack_attn(w, x), tt);
+                fma4(acc, w, r[k]);
             }
         }
     }
@@ -231,7 +331,7 @@ __global__ __launch_bounds__(256) void k_bwd_src_heavy2(BwdArgs a) {
     }
 }
 
-// ---- destination pass: softmax backward over the streamed [E,H] arrays -----------------------
+// ---- per-edge [H] vectors ------------------------------------------------------------------------
 template <int H> struct HeadVec {
     float v[H];
 };
@@ -255,132 +355,117 @@ template <int H> __device__ __forceinline__ void sth(float *p, const HeadVec<H> 
     }
 }
 
-// one thread per destination node with <= light_max in-edges
-template <int H>
-__global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a, int C) {
-    for (int vi = blockIdx.x * 256 + threadIdx.x; vi < a.N; vi += gridDim.x * 256) {
-        const int v = vi;  // one thread per node: neighbouring threads read neighbouring segments
-        const int b = a.pin.ptr[v], e = a.pin.ptr[v + 1];
-        if (e - b > a.pin.light_max) continue;
-        HeadVec<H> delta, det;
+// the (a, t) pairs of one edge: ap = packed attention weights, tt = SDDMM terms
+template <int H> struct PairVec {
+    HeadVec<H> ap, tt;
+};
+template <int H> __device__ __forceinline__ PairVec<H> ld_pairs(const float *pairs, int64_t slot) {
+    PairVec<H> r;
+    const float *p = pairs + slot * (2 * H);
+    if (H == 4) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(p), q1 = *reinterpret_cast<const float4 *>(p + 4);
+        r.ap.v[0] = q0.x, r.tt.v[0] = q0.y, r.ap.v[1 % H] = q0.z, r.tt.v[1 % H] = q0.w;
+        r.ap.v[2 % H] = q1.x, r.tt.v[2 % H] = q1.y, r.ap.v[3 % H] = q1.z, r.tt.v[3 % H] = q1.w;
+    } else {
 #pragma unroll
-        for (int h = 0; h < H; ++h) delta.v[h] = det.v[h] = 0.f;
-        if (e == b) {
-            sth<H>(a.d_y + (int64_t)v * a.ld_dy + C + H, det);
-            continue;
+        for (int h = 0; h < H; ++h) {
+            const float2 q = *reinterpret_cast<const float2 *>(p + 2 * h);
+            r.ap.v[h] = q.x, r.tt.v[h] = q.y;
         }
-        if (e - b <= 4) {
-            // short segment (the common case): one batch of clamped loads, everything in registers
-            HeadVec<H> ap[4], tt[4];
+    }
+    return r;
+}
+
+// ---- destination pass: delta_v and d_et[v] from the pairs of the in-edges ------------------------
+// With lk_e = leaky'_e (1 or the slope) the segment sums
+//     S_at = sum a_e t_e,   S_atl = sum a_e t_e lk_e,   S_al = sum a_e lk_e
+// give delta_v = S_at and d_et[v] = sum a_e (t_e - delta_v) lk_e = S_atl - delta_v S_al: one pass over
+// the gathered pairs, no second visit once delta_v is known.
+template <int H> struct DstSums {
+    float at[H], atl[H], al[H];
+};
+template <int H> __device__ __forceinline__ void dst_zero(DstSums<H> &s) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ii = min(b + k, e - 1);
-                ap[k] = ldh<H>(a.attn + (int64_t)ii * H);
-                tt[k] = ldh<H>(a.t + (int64_t)ii * H);
-            }
+    for (int h = 0; h < H; ++h) s.at[h] = s.atl[h] = s.al[h] = 0.f;
+}
+template <int H> __device__ __forceinline__ void dst_add(DstSums<H> &s, const PairVec<H> &p, float slope, bool on) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int h = 0; h < H; ++h)
-                    delta.v[h] = b + k < e ? fmaf(fabsf(ap[k].v[h]), tt[k].v[h], delta.v[h]) : delta.v[h];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (b + k < e) {
-                    HeadVec<H> dl;
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        float d = fabsf(ap[k].v[h]) * (tt[k].v[h] - delta.v[h]);
-                        if (attn_neg(ap[k].v[h])) d *= a.slope;
-                        dl.v[h] = d;
-                        det.v[h] += d;
-                    }
-                    sth<H>(a.dl + (int64_t)(b + k) * H, dl);
-                }
-            }
-        } else {
-            for (int i = b; i < e; ++i) {
-                const HeadVec<H> ap = ldh<H>(a.attn + (int64_t)i * H), tt = ldh<H>(a.t + (int64_t)i * H);
-#pragma unroll
-                for (int h = 0; h < H; ++h) delta.v[h] = fmaf(fabsf(ap.v[h]), tt.v[h], delta.v[h]);
-            }
-            for (int i = b; i < e; ++i) {
-                const HeadVec<H> ap = ldh<H>(a.attn + (int64_t)i * H), tt = ldh<H>(a.t + (int64_t)i * H);
-                HeadVec<H> dl;
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    float d = fabsf(ap.v[h]) * (tt.v[h] - delta.v[h]);
-                    if (attn_neg(ap.v[h])) d *= a.slope;
-                    dl.v[h] = d;
-                    det.v[h] += d;
-                }
-                sth<H>(a.dl + (int64_t)i * H, dl);
-            }
-        }
-        sth<H>(a.d_y + (int64_t)v * a.ld_dy + C + H, det);
+    for (int h = 0; h < H; ++h) {
+        const float w = on ? fabsf(p.ap.v[h]) : 0.f;
+        const float wl = attn_neg(p.ap.v[h]) ? w * slope : w;
+        s.at[h] = fmaf(w, p.tt.v[h], s.at[h]);
+        s.atl[h] = fmaf(wl, p.tt.v[h], s.atl[h]);
+        s.al[h] += wl;
     }
 }
 
-// heavy destinations, step 1: wave per chunk, lane per edge: the chunk's sum of a * t
+// W lanes per destination node with <= light_max in-edges; the lanes take the in-edges round robin
+// (one gathered pair per lane and round: the loads of a segment are in flight together) and combine
+// with a fixed DPP butterfly.  Nodes are walked by segment-length class.
+constexpr int DST_W = 8;
+template <int H>
+__global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a, int C) {
+    constexpr int W = DST_W, NPB = 256 / W;
+    const int q = threadIdx.x % W, slot = threadIdx.x / W;
+    for (int vi = blockIdx.x * NPB + slot; vi < a.N; vi += gridDim.x * NPB) {
+        const int v = a.pin.order ? a.pin.order[vi] : vi;
+        const int b = a.pin.ptr[v], e = a.pin.ptr[v + 1];
+        if (e - b > a.pin.light_max) continue;
+        DstSums<H> s;
+        dst_zero<H>(s);
+        if (e - b > 0) {
+            int i = b + q;
+            for (; i + W < e; i += 2 * W) {  // two rounds per trip: four independent gathers in flight
+                const PairVec<H> p0 = ld_pairs<H>(a.pairs, a.in_pos[i]), p1 = ld_pairs<H>(a.pairs, a.in_pos[i + W]);
+                dst_add<H>(s, p0, a.slope, true);
+                dst_add<H>(s, p1, a.slope, true);
+            }
+            const PairVec<H> p = ld_pairs<H>(a.pairs, a.in_pos[min(i, e - 1)]);
+            dst_add<H>(s, p, a.slope, i < e);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                s.at[h] = head_sum<W>(s.at[h]);
+                s.atl[h] = head_sum<W>(s.atl[h]);
+                s.al[h] = head_sum<W>(s.al[h]);
+            }
+        }
+        if (q == 0) {
+            HeadVec<H> delta, det;
+#pragma unroll
+            for (int h = 0; h < H; ++h) delta.v[h] = s.at[h], det.v[h] = s.atl[h] - s.at[h] * s.al[h];
+            sth<H>(a.delta + (int64_t)v * H, delta);
+            sth<H>(a.d_y + (int64_t)v * a.ld_dy + C + H, det);
+        }
+    }
+}
+
+// heavy destinations, step 1: wave per chunk, lane per edge: the chunk's three sums
 template <int H>
 __global__ __launch_bounds__(256) void k_bwd_dst_heavy1(BwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= a.pin.n_chunks) return;
     const int beg = a.pin.chunk_beg[c], end = a.pin.chunk_end[c];
-    float delta[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) delta[h] = 0.f;
+    DstSums<H> s;
+    dst_zero<H>(s);
     for (int i = beg + lane; i < end; i += 64) {
-        const HeadVec<H> ap = ldh<H>(a.attn + (int64_t)i * H), tt = ldh<H>(a.t + (int64_t)i * H);
-#pragma unroll
-        for (int h = 0; h < H; ++h) delta[h] = fmaf(fabsf(ap.v[h]), tt.v[h], delta[h]);
+        const PairVec<H> p = ld_pairs<H>(a.pairs, a.in_pos[i]);
+        dst_add<H>(s, p, a.slope, true);
     }
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-        const float d = wave_sum(delta[h]);
-        if (lane == 0) a.ws_delta[(int64_t)c * H + h] = d;
-    }
-}
-
-// step 2: wave per chunk, lane per edge: node delta (chunk order), d_logit, chunk d_et
-template <int H>
-__global__ __launch_bounds__(256) void k_bwd_dst_heavy2(BwdArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= a.pin.n_chunks) return;
-    const int slot = a.pin.chunk_node[c];
-    const int c0 = a.pin.heavy_cptr[slot], c1 = a.pin.heavy_cptr[slot + 1];
-    const int beg = a.pin.chunk_beg[c], end = a.pin.chunk_end[c];
-    float delta[H], det[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-        float t = 0.f;
-        for (int k = c0 + lane; k < c1; k += 64) t += a.ws_delta[(int64_t)k * H + h];
-        delta[h] = wave_sum(t);
-        det[h] = 0.f;
-    }
-    for (int i = beg + lane; i < end; i += 64) {
-        const HeadVec<H> ap = ldh<H>(a.attn + (int64_t)i * H), tt = ldh<H>(a.t + (int64_t)i * H);
-        HeadVec<H> dl;
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            float d = fabsf(ap.v[h]) * (tt.v[h] - delta[h]);
-            if (attn_neg(ap.v[h])) d *= a.slope;
-            dl.v[h] = d;
-            det[h] += d;
+        const float x = wave_sum(s.at[h]), y = wave_sum(s.atl[h]), z = wave_sum(s.al[h]);
+        if (lane == 0) {
+            a.ws_delta[(int64_t)c * H + h] = x;
+            a.ws_det[((int64_t)c * H + h) * 2] = y;
+            a.ws_det[((int64_t)c * H + h) * 2 + 1] = z;
         }
-        sth<H>(a.dl + (int64_t)i * H, dl);
-    }
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-        float t = wave_sum(det[h]);
-        if (lane == 0) a.ws_det[(int64_t)c * H + h] = t;
     }
 }
 
-// step 3: wave per heavy node: d_et = sum of chunk partials in chunk order
+// step 2: wave per heavy node: the chunk sums in chunk order -> delta_v, d_et[v]
 template <int H>
-__global__ __launch_bounds__(256) void k_bwd_dst_heavy3(BwdArgs a, int C) {
+__global__ __launch_bounds__(256) void k_bwd_dst_heavy2(BwdArgs a, int C) {
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= a.pin.n_heavy) return;
@@ -388,33 +473,78 @@ __global__ __launch_bounds__(256) void k_bwd_dst_heavy3(BwdArgs a, int C) {
     const int v = a.pin.heavy_node[slot];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-        float t = 0.f;
-        for (int k = c0 + lane; k < c1; k += 64) t += a.ws_det[(int64_t)k * H + h];
-        t = wave_sum(t);
-        if (lane == 0) a.d_y[(int64_t)v * a.ld_dy + C + H + h] = t;
+        float x = 0.f, y = 0.f, z = 0.f;
+        for (int k = c0 + lane; k < c1; k += 64) {
+            x += a.ws_delta[(int64_t)k * H + h];
+            y += a.ws_det[((int64_t)k * H + h) * 2];
+            z += a.ws_det[((int64_t)k * H + h) * 2 + 1];
+        }
+        x = wave_sum(x), y = wave_sum(y), z = wave_sum(z);
+        if (lane == 0) {
+            a.delta[(int64_t)v * H + h] = x;
+            a.d_y[(int64_t)v * a.ld_dy + C + H + h] = y - x * z;
+        }
     }
 }
 
-// ---- source pass 2: d_eh[u] = sum over out-edges of d_logit -----------------------------------
+// ---- source pass 2: d_logit of every out-edge from the streamed (a, t) pairs and the destination's
+// delta; d_eh[u] = sum over out-edges of d_logit ------------------------------------------------
+template <int H>
+__device__ __forceinline__ HeadVec<H> edge_dlogit(const BwdArgs &a, int j) {
+    const PairVec<H> p = ld_pairs<H>(a.pairs, j);
+    const HeadVec<H> dv = ldh<H>(a.delta + (int64_t)a.out_dst[j] * H);
+    HeadVec<H> d;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float x = fabsf(p.ap.v[h]) * (p.tt.v[h] - dv.v[h]);
+        if (attn_neg(p.ap.v[h])) x *= a.slope;
+        d.v[h] = x;
+    }
+    sth<H>(a.dl_csr + (int64_t)j * H, d);
+    if (a.dl) sth<H>(a.dl + (int64_t)a.out_pos[j] * H, d);
+    return d;
+}
+
+// W lanes per source node with <= light_max out-edges, two edges per lane and round: their loads are
+// issued before the first d_logit is stored
+constexpr int DEH_W = 4;
 template <int H>
 __global__ __launch_bounds__(256) void k_bwd_deh_light(BwdArgs a, int C) {
-    for (int ui = blockIdx.x * 256 + threadIdx.x; ui < a.N; ui += gridDim.x * 256) {
-        const int u = ui;
+    constexpr int W = DEH_W, NPB = 256 / W;
+    const int q = threadIdx.x % W, slot = threadIdx.x / W;
+    for (int ui = blockIdx.x * NPB + slot; ui < a.N; ui += gridDim.x * NPB) {
+        const int u = ui;  // natural order: neighbouring groups stream neighbouring segments
         const int b = a.pout.ptr[u], e = a.pout.ptr[u + 1];
         if (e - b > a.pout.light_max) continue;
         HeadVec<H> s;
 #pragma unroll
         for (int h = 0; h < H; ++h) s.v[h] = 0.f;
-        for (int j = b; j < e; j += 4) {
-            HeadVec<H> d[4];
+        for (int j = b + q; j < e; j += 2 * W) {
+            const int j1 = min(j + W, e - 1);
+            const PairVec<H> p0 = ld_pairs<H>(a.pairs, j), p1 = ld_pairs<H>(a.pairs, j1);
+            const HeadVec<H> dv0 = ldh<H>(a.delta + (int64_t)a.out_dst[j] * H);
+            const HeadVec<H> dv1 = ldh<H>(a.delta + (int64_t)a.out_dst[j1] * H);
+            const int pos0 = a.dl ? a.out_pos[j] : 0, pos1 = a.dl ? a.out_pos[j1] : 0;
+            HeadVec<H> d0, d1;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] = ldh<H>(a.dl + (int64_t)a.out_pos[min(j + k, e - 1)] * H);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int h = 0; h < H; ++h) s.v[h] += j + k < e ? d[k].v[h] : 0.f;
+            for (int h = 0; h < H; ++h) {
+                float x0 = fabsf(p0.ap.v[h]) * (p0.tt.v[h] - dv0.v[h]);
+                float x1 = fabsf(p1.ap.v[h]) * (p1.tt.v[h] - dv1.v[h]);
+                if (attn_neg(p0.ap.v[h])) x0 *= a.slope;
+                if (attn_neg(p1.ap.v[h])) x1 *= a.slope;
+                d0.v[h] = x0, d1.v[h] = x1;
+                s.v[h] += x0 + (j + W < e ? x1 : 0.f);
+            }
+            sth<H>(a.dl_csr + (int64_t)j * H, d0);
+            if (a.dl) sth<H>(a.dl + (int64_t)pos0 * H, d0);
+            if (j + W < e) {
+                sth<H>(a.dl_csr + (int64_t)(j + W) * H, d1);
+                if (a.dl) sth<H>(a.dl + (int64_t)pos1 * H, d1);
+            }
         }
-        sth<H>(a.d_y + (int64_t)u * a.ld_dy + C, s);
+#pragma unroll
+        for (int h = 0; h < H; ++h) s.v[h] = head_sum<W>(s.v[h]);
+        if (q == 0) sth<H>(a.d_y + (int64_t)u * a.ld_dy + C, s);
     }
 }
 
@@ -428,7 +558,7 @@ __global__ __launch_bounds__(256) void k_bwd_deh_heavy1(BwdArgs a) {
 #pragma unroll
     for (int h = 0; h < H; ++h) s[h] = 0.f;
     for (int j = beg + lane; j < end; j += 64) {
-        const HeadVec<H> d = ldh<H>(a.dl + (int64_t)a.out_pos[j] * H);
+        const HeadVec<H> d = edge_dlogit<H>(a, j);
 #pragma unroll
         for (int h = 0; h < H; ++h) s[h] += d.v[h];
     }
@@ -456,6 +586,7 @@ __global__ __launch_bounds__(256) void k_bwd_deh_heavy2(BwdArgs a, int C) {
 }
 
 // ---- d_ee_table[t,h] = sum over edges of type t of d_logit[e,h] ---------------------------
+// (edges are walked in CSR order: d_logit and the edge types both come in that order.)
 // Every thread owns a private column of an LDS table [e_dim*H][128] (bank = thread: no conflicts,
 // no atomics) and adds its edges there in edge order; the 128 columns of a row are then summed
 // in a fixed tree and a last launch adds the block rows.
@@ -471,7 +602,7 @@ __global__ __launch_bounds__(TBL_THREADS) void k_bwd_table_partial(BwdArgs a) {
     int i = blockIdx.x * TBL_THREADS + tid;
     for (; i + stride < a.E; i += 2 * stride) {  // two edges per round: their loads are in flight together
         const int t0 = a.etype[i], t1 = a.etype[i + stride];
-        const HeadVec<H> d0 = ldh<H>(a.dl + (int64_t)i * H), d1 = ldh<H>(a.dl + (int64_t)(i + stride) * H);
+        const HeadVec<H> d0 = ldh<H>(a.dl_csr + (int64_t)i * H), d1 = ldh<H>(a.dl_csr + (int64_t)(i + stride) * H);
 #pragma unroll
         for (int h = 0; h < H; ++h) tbl[(t0 * H + h) * TBL_THREADS + tid] += d0.v[h];
 #pragma unroll
@@ -479,7 +610,7 @@ __global__ __launch_bounds__(TBL_THREADS) void k_bwd_table_partial(BwdArgs a) {
     }
     if (i < a.E) {
         const int t0 = a.etype[i];
-        const HeadVec<H> d0 = ldh<H>(a.dl + (int64_t)i * H);
+        const HeadVec<H> d0 = ldh<H>(a.dl_csr + (int64_t)i * H);
 #pragma unroll
         for (int h = 0; h < H; ++h) tbl[(t0 * H + h) * TBL_THREADS + tid] += d0.v[h];
     }
@@ -527,7 +658,7 @@ int launch_table(BwdArgs &a, hipStream_t stream) {
     return MAGIC_OK;
 }
 
-template <int H, int LPH>
+template <int H, int LPH, bool TABLE>
 int launch_bwd(BwdArgs &a, hipStream_t stream) {
     constexpr int C = H * LPH * 4;
     constexpr int NPB = 256 / (H * LPH);
@@ -536,21 +667,25 @@ int launch_bwd(BwdArgs &a, hipStream_t stream) {
         if (a.d_bias || a.d_prelu)
             MAGIC_LAUNCH("gat_bwd_reduce_bias", k_bwd_reduce_bias, C + 1, 256, 0, stream, a, C);
     }
-    MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_light<H, LPH>), stride_grid(a.N, NPB, 256 * 16), 256, 0, stream, a);
+    if (a.E == 0) {  // no edges: d_hs = d_eh = d_et = 0 and an all-zero edge-type table
+        if (hipMemset2DAsync(a.d_y, sizeof(float) * a.ld_dy, 0, sizeof(float) * (C + 2 * H), a.N, stream) != hipSuccess)
+            return MAGIC_ERR_RUNTIME;
+        int st0 = launch_table<H, LPH>(a, stream);
+        return st0 != MAGIC_OK ? st0 : launch_status();
+    }
+    MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_light<H, LPH, TABLE>), stride_grid(a.N, NPB, 256 * 16), 256, 0, stream, a);
     if (a.pout.n_chunks > 0) {
         const int cgrid = (a.pout.n_chunks + 3) / 4;
-        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_heavy1", H, LPH) : "gat_bwd_src_heavy1", (k_bwd_src_heavy1<H, LPH>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_heavy1", H, LPH) : "gat_bwd_src_heavy1", (k_bwd_src_heavy1<H, LPH, TABLE>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_bwd_src_heavy2", (k_bwd_src_heavy2<H, LPH>), a.pout.n_heavy, 256, 0, stream, a);
     }
-    const int ngrid = stride_grid(a.N, 256, 256 * 16);
-    MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_dst_light", H, LPH) : "gat_bwd_dst_light", (k_bwd_dst_light<H>), ngrid, 256, 0, stream, a, C);
+    MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_dst_light", H, LPH) : "gat_bwd_dst_light", (k_bwd_dst_light<H>), stride_grid(a.N, 256 / DST_W, 256 * 32), 256, 0, stream, a, C);
     if (a.pin.n_chunks > 0) {
         const int cgrid = (a.pin.n_chunks + 3) / 4;
         MAGIC_LAUNCH("gat_bwd_dst_heavy1", (k_bwd_dst_heavy1<H>), cgrid, 256, 0, stream, a);
-        MAGIC_LAUNCH("gat_bwd_dst_heavy2", (k_bwd_dst_heavy2<H>), cgrid, 256, 0, stream, a);
-        MAGIC_LAUNCH("gat_bwd_dst_heavy3", (k_bwd_dst_heavy3<H>), (a.pin.n_heavy + 3) / 4, 256, 0, stream, a, C);
+        MAGIC_LAUNCH("gat_bwd_dst_heavy2", (k_bwd_dst_heavy2<H>), (a.pin.n_heavy + 3) / 4, 256, 0, stream, a, C);
     }
-    MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_deh_light", H, LPH) : "gat_bwd_deh_light", (k_bwd_deh_light<H>), ngrid, 256, 0, stream, a, C);
+    MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_deh_light", H, LPH) : "gat_bwd_deh_light", (k_bwd_deh_light<H>), stride_grid(a.N, 256 / DEH_W, 256 * 32), 256, 0, stream, a, C);
     if (a.pout.n_chunks > 0) {
         MAGIC_LAUNCH("gat_bwd_deh_heavy1", (k_bwd_deh_heavy1<H>), (a.pout.n_chunks + 3) / 4, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_bwd_deh_heavy2", (k_bwd_deh_heavy2<H>), (a.pout.n_heavy + 3) / 4, 256, 0, stream, a, C);
@@ -574,35 +709,40 @@ size_t magic_gat_bwd_workspace_bytes(int32_t N, int32_t E, int32_t n_chunks_in, 
     using namespace magic;
     if (N <= 0 || H <= 0 || D <= 0) return 256;
     const size_t C = (size_t)H * D, f = sizeof(float);
+    const size_t En = E > 0 ? E : 1;
     size_t gl = light_grid(N, H, D), gt = table_grid(E);
     size_t b = align_up(gl * C * f) + align_up(gl * f);
-    b += 2 * align_up((size_t)(n_chunks_in > 0 ? n_chunks_in : 1) * H * f);
+    b += align_up((size_t)(n_chunks_in > 0 ? n_chunks_in : 1) * H * f) +
+         align_up((size_t)(n_chunks_in > 0 ? n_chunks_in : 1) * H * 2 * f);
     b += align_up((size_t)(n_chunks_out > 0 ? n_chunks_out : 1) * C * f) +
          align_up((size_t)(n_chunks_out > 0 ? n_chunks_out : 1) * H * f);
     b += align_up(gt * (size_t)(e_dim > 0 ? e_dim : 1) * H * f);
-    b += align_up((size_t)(E > 0 ? E : 1) * H * f);
+    b += align_up(En * H * 2 * f) + align_up(En * H * f) + align_up((size_t)N * H * f);
     return b + 256;
 }
 
-int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_src,
+int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_pos,
                   const magic_plan *out_plan, const int32_t *out_dst, const int32_t *out_pos, const float *hs,
-                  int64_t ld_hs, const float *attn, const int32_t *etype_csc, int32_t e_dim, float slope,
-                  const float *pre, const float *act_out, int64_t ld_act, const float *prelu_w,
-                  const float *d_out, int64_t ld_dout, float *d_pre,
-                  int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table, float *d_logit, float *d_bias, float *d_prelu_w,
-                  void *workspace, size_t workspace_bytes, void *stream_) {
+                  int64_t ld_hs, const float *eh, int64_t ld_score, const float *stat, const float *ee_table,
+                  const int32_t *etype_csr, const float *ee_csc, int32_t e_dim, float slope, const float *pre,
+                  const float *act_out, int64_t ld_act, const float *prelu_w, const float *d_out, int64_t ld_dout,
+                  float *d_pre, int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table, float *d_logit,
+                  float *d_bias, float *d_prelu_w, void *workspace, size_t workspace_bytes, void *stream_) {
     using namespace magic;
     if (N < 0 || E < 0 || H <= 0 || D <= 0) return MAGIC_ERR_INVALID_ARG;
     if (!shape_supported(H, D)) return MAGIC_ERR_UNSUPPORTED;
     if (N == 0) return MAGIC_OK;
     const int C = H * D;
     if (!plan_valid(in_plan) || !plan_valid(out_plan) || !hs || !d_out || !d_pre || !d_y) return MAGIC_ERR_INVALID_ARG;
-    if (E > 0 && (!out_dst || !out_pos || !attn || !d_logit)) return MAGIC_ERR_INVALID_ARG;
+    const bool table = ee_table != nullptr;
+    if (E > 0 && (!in_pos || !out_dst || !out_pos || !eh || !stat || ld_score < H)) return MAGIC_ERR_INVALID_ARG;
+    if (E > 0 && table && !etype_csr) return MAGIC_ERR_INVALID_ARG;
+    if (E > 0 && !table && !ee_csc) return MAGIC_ERR_INVALID_ARG;
+    if (table && (e_dim <= 0 || e_dim > MAX_E_DIM)) return MAGIC_ERR_UNSUPPORTED;
     if (prelu_w && (!pre || !act_out || ld_act < C || (ld_act & 3))) return MAGIC_ERR_INVALID_ARG;
     if (prelu_w && d_pre == d_out) return MAGIC_ERR_INVALID_ARG;  // in-place only without an activation
     if (ld_hs < C || ld_dout < C || ld_dy < C + 2 * H || ld_dpre < C) return MAGIC_ERR_INVALID_ARG;
     if ((ld_hs | ld_dout | ld_dy | ld_dpre) & 3) return MAGIC_ERR_INVALID_ARG;
-    if (etype_csc && d_ee_table && (e_dim <= 0 || e_dim > 32)) return MAGIC_ERR_UNSUPPORTED;
     BwdArgs a;
     a.N = N;
     a.E = E;
@@ -610,10 +750,15 @@ int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     a.pout = plan_dev(out_plan);
     a.out_dst = out_dst;
     a.out_pos = out_pos;
+    a.in_pos = in_pos;
     a.hs = hs;
     a.ld_hs = ld_hs;
-    a.attn = attn;
-    a.etype = etype_csc;
+    a.eh = eh;
+    a.ld_s = ld_score;
+    a.stat = stat;
+    a.ee_table = ee_table;
+    a.etype = table ? etype_csr : nullptr;
+    a.ee = ee_csc;
     a.e_dim = e_dim;
     a.slope = slope;
     a.pre = pre;
@@ -626,26 +771,30 @@ int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     a.ld_dpre = ld_dpre;
     a.d_y = d_y;
     a.ld_dy = ld_dy;
-    a.d_table = d_ee_table;
+    a.d_table = table ? d_ee_table : nullptr;
     a.dl = d_logit;
     a.d_bias = d_bias;
     a.d_prelu = d_prelu_w;
     a.grid_light = light_grid(N, H, D);
     a.grid_table = table_grid(E);
+    const size_t En = E > 0 ? E : 1;
     Arena ar(workspace, workspace_bytes);
     a.ws_bias = ar.take<float>((size_t)a.grid_light * C);
     a.ws_prelu = ar.take<float>((size_t)a.grid_light);
     a.ws_delta = ar.take<float>((size_t)(a.pin.n_chunks > 0 ? a.pin.n_chunks : 1) * H);
-    a.ws_det = ar.take<float>((size_t)(a.pin.n_chunks > 0 ? a.pin.n_chunks : 1) * H);
+    a.ws_det = ar.take<float>((size_t)(a.pin.n_chunks > 0 ? a.pin.n_chunks : 1) * H * 2);
     a.ws_acc = ar.take<float>((size_t)(a.pout.n_chunks > 0 ? a.pout.n_chunks : 1) * C);
     a.ws_deh = ar.take<float>((size_t)(a.pout.n_chunks > 0 ? a.pout.n_chunks : 1) * H);
     a.ws_table = ar.take<float>((size_t)a.grid_table * (e_dim > 0 ? e_dim : 1) * H);
-    a.t = ar.take<float>((size_t)(E > 0 ? E : 1) * H);
+    a.pairs = ar.take<float>(En * H * 2);
+    a.dl_csr = ar.take<float>(En * H);
+    a.delta = ar.take<float>((size_t)N * H);
     if (!ar.ok()) return MAGIC_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int lph = D / 4;
-#define X(h, l) \
-    if (H == h && lph == l) return launch_bwd<h, l>(a, stream);
+#define X(h, l)                                                \
+    if (H == h && lph == l)                                    \
+        return table ? launch_bwd<h, l, true>(a, stream) : launch_bwd<h, l, false>(a, stream);
     MAGIC_GAT_SHAPES(X)
 #undef X
     return MAGIC_ERR_UNSUPPORTED;

@@ -59,6 +59,12 @@ __device__ __forceinline__ void st4_nt(float *p, float4 v) {
     t.x = v.x, t.y = v.y, t.z = v.z, t.w = v.w;
     __builtin_nontemporal_store(t, reinterpret_cast<f4v_t *>(p));
 }
+typedef float f2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st2_nt(float *p, float a, float b) {
+    f2v_t t;
+    t.x = a, t.y = b;
+    __builtin_nontemporal_store(t, reinterpret_cast<f2v_t *>(p));
+}
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void fma4(float4 &acc, float a, float4 r) {
     acc.x = fmaf(a, r.x, acc.x);

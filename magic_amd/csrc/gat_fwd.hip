@@ -37,7 +37,8 @@ struct FwdArgs {
     float *out;
     int64_t ld_out;
     float *pre;   // [N,C] or null
-    float *attn;  // [E,H]
+    float *attn;  // [E,H] or null
+    float *stat;  // [N,H,2] per destination and head: (et, max + log sum exp of its in-edge logits), or null
     float *x;         // [E,H] raw logits (workspace)
     float *ws_stats;  // [n_chunks,H,2]
     float *ws_acc;    // [n_chunks,C]
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
         const int deg = e - b;
         if (deg > a.plan.light_max) continue;
         float4 acc = f4zero();
+        float lse = 0.f;
         if (deg > 0 && deg <= 4) {
             // short segment (the common case): one batch of clamped loads, one dependent chain
             float x[4], l[4], p[4];
@@ -125,11 +127,13 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
                 s += p[j];
             }
             const float inv = 1.f / s;
+            lse = m + logf(s);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j < deg) {
                     const float w = p[j] * inv;
-                    if (writer) __builtin_nontemporal_store(pack_attn(w, x[j]), a.attn + (int64_t)(b + j) * H + h);
+                    if (writer && a.attn)
+                        __builtin_nontemporal_store(pack_attn(w, x[j]), a.attn + (int64_t)(b + j) * H + h);
                     fma4(acc, w, r[j]);
                 }
             }
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
             for (int i = b + q; i < e; i += LPH) s += __expf(leaky(a.x[(int64_t)i * H + h], a.slope) - m);
             s = head_sum<LPH>(s);
             const float inv = 1.f / s;
+            lse = m + logf(s);
             int i = b;
             for (; i + 4 <= e; i += 4) {
                 float4 r[4];
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     w[j] = __expf(leaky(x[j], a.slope) - m) * inv;
-                    if (writer) a.attn[(int64_t)(i + j) * H + h] = pack_attn(w[j], x[j]);
+                    if (writer && a.attn) a.attn[(int64_t)(i + j) * H + h] = pack_attn(w[j], x[j]);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) fma4(acc, w[j], r[j]);
@@ -170,12 +175,15 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
                 for (int j = 0; j < 3; ++j) {
                     if (i + j < e) {
                         const float w = __expf(leaky(x[j], a.slope) - m) * inv;
-                        if (writer) a.attn[(int64_t)(i + j) * H + h] = pack_attn(w, x[j]);
+                        if (writer && a.attn) a.attn[(int64_t)(i + j) * H + h] = pack_attn(w, x[j]);
                         fma4(acc, w, r[j]);
                     }
                 }
             }
         }
+        if (writer && a.stat)
+            *reinterpret_cast<float2 *>(a.stat + ((int64_t)v * H + h) * 2) =
+                make_float2(a.et[(int64_t)v * a.ld_s + h], lse);
         epilogue<H, LPH>(a, v, g, acc);
     }
 }
@@ -261,6 +269,11 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
         }
     const float inv = 1.f / s;
     const bool writer = (g % LPH) == 0;
+    if (a.stat && c == a.plan.heavy_cptr[slot] && sg == 0 && writer) {  // the node's first chunk records its statistics
+        const int v = a.plan.heavy_node[slot];
+        *reinterpret_cast<float2 *>(a.stat + ((int64_t)v * H + h) * 2) =
+            make_float2(a.et[(int64_t)v * a.ld_s + h], m + logf(s));
+    }
     float4 acc = f4zero();
     int i = beg + sg;
     for (; i + 3 * NSG < end; i += 4 * NSG) {
@@ -273,7 +286,7 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             w[j] = __expf(leaky(x[j], a.slope) - m) * inv;
-            if (writer) a.attn[(int64_t)(i + j * NSG) * H + h] = pack_attn(w[j], x[j]);
+            if (writer && a.attn) a.attn[(int64_t)(i + j * NSG) * H + h] = pack_attn(w[j], x[j]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) fma4(acc, w[j], r[j]);
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
         float4 r = ld4(a.hs + (int64_t)a.src[i] * a.ld_hs + g * 4);
         float x = a.x[(int64_t)i * H + h];
         float w = __expf(leaky(x, a.slope) - m) * inv;
-        if (writer) a.attn[(int64_t)i * H + h] = pack_attn(w, x);
+        if (writer && a.attn) a.attn[(int64_t)i * H + h] = pack_attn(w, x);
         fma4(acc, w, r);
     }
     acc = substream_sum4<G>(acc);
@@ -351,14 +364,14 @@ int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
                   int64_t ld_score, const float *ee_table, const int32_t *etype_csc, const float *ee_csc,
                   float slope, const float *bias, const float *res, int64_t ld_res, const uint8_t *res_mask,
                   float res_scale, const float *prelu_w,
-                  float *out, int64_t ld_out, float *pre, float *attn, void *workspace, size_t workspace_bytes,
-                  void *stream_) {
+                  float *out, int64_t ld_out, float *pre, float *attn, float *stat, void *workspace,
+                  size_t workspace_bytes, void *stream_) {
     using namespace magic;
     if (N < 0 || E < 0 || H <= 0 || D <= 0) return MAGIC_ERR_INVALID_ARG;
     if (!shape_supported(H, D)) return MAGIC_ERR_UNSUPPORTED;
     if (N == 0) return MAGIC_OK;
     if (!plan_valid(in_plan) || !hs || !eh || !et || !out) return MAGIC_ERR_INVALID_ARG;
-    if (E > 0 && (!in_src || !in_dst || !attn)) return MAGIC_ERR_INVALID_ARG;
+    if (E > 0 && (!in_src || !in_dst)) return MAGIC_ERR_INVALID_ARG;
     const bool table = ee_table != nullptr;
     if (E > 0 && table && !etype_csc) return MAGIC_ERR_INVALID_ARG;
     if (E > 0 && !table && !ee_csc) return MAGIC_ERR_INVALID_ARG;
@@ -390,6 +403,7 @@ int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     a.ld_out = ld_out;
     a.pre = pre;
     a.attn = attn;
+    a.stat = stat;
     a.ws_stats = a.ws_acc = nullptr;
     Arena ar(workspace, workspace_bytes);
     a.x = ar.take<float>((size_t)(E > 0 ? E : 1) * H);

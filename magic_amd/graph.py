@@ -122,8 +122,9 @@ class Structure:
             self.check_endpoints()
         # CSC: edges sorted by destination (ties keep ascending edge id)
         self.in_ptr = self.in_src = self.in_eid = self.in_dst = None
-        # CSR: edges sorted by source; out_pos = position of that edge in CSC order
-        self.out_ptr = self.out_dst = self.out_eid = self.out_pos = None
+        # CSR: edges sorted by source; out_pos = position of that edge in CSC order, in_pos = position
+        # of every CSC edge in CSR order (the inverse permutation)
+        self.out_ptr = self.out_dst = self.out_eid = self.out_pos = self.in_pos = None
         self.plan_in: Optional[SegmentPlan] = None
         self.plan_out: Optional[SegmentPlan] = None
 
@@ -153,6 +154,8 @@ class Structure:
         inv = torch.empty(self.num_edges, dtype=torch.int32, device=in_eid.device)
         inv[in_eid.long()] = torch.arange(self.num_edges, dtype=torch.int32, device=in_eid.device)
         self.out_pos = inv[out_eid.long()].contiguous()
+        self.in_pos = torch.empty_like(self.out_pos)
+        self.in_pos[self.out_pos.long()] = torch.arange(self.num_edges, dtype=torch.int32, device=in_eid.device)
         self.plan_in = build_segment_plan(in_ptr)
         self.plan_out = build_segment_plan(out_ptr)
 
@@ -176,7 +179,7 @@ class Structure:
         if self.has_csr():
             s.in_ptr, s.in_src, s.in_eid = (t.to(device) for t in (self.in_ptr, self.in_src, self.in_eid))
             s.out_ptr, s.out_dst, s.out_eid = (t.to(device) for t in (self.out_ptr, self.out_dst, self.out_eid))
-            s.out_pos = self.out_pos.to(device)
+            s.out_pos, s.in_pos = self.out_pos.to(device), self.in_pos.to(device)
             s.in_dst = self.in_dst.to(device)
             s.plan_in, s.plan_out = self.plan_in.to(device), self.plan_out.to(device)
         return s
@@ -300,6 +303,15 @@ class Graph:
     def edge_types_csc(self) -> Optional[torch.Tensor]:
         """Edge type ids (int32) in CSC order when ``edata['attr']`` is the one-hot of an
         integer type (``utils/loaddata.py:259``); ``None`` for dense edge attributes."""
+        both = self._edge_types()
+        return None if both is None else both[0]
+
+    def edge_types_csr(self) -> Optional[torch.Tensor]:
+        """The same ids in CSR order (what the backward sweeps stream)."""
+        both = self._edge_types()
+        return None if both is None else both[1]
+
+    def _edge_types(self):
         attr = self.edata.get("attr")
         if attr is None:
             return None
@@ -331,7 +343,8 @@ class Graph:
         res = None
         if types is not None:
             s = self._s.ensure_csr()
-            res = types.to(torch.int32)[s.in_eid.long()].contiguous()
+            t32 = types.to(torch.int32)
+            res = (t32[s.in_eid.long()].contiguous(), t32[s.out_eid.long()].contiguous())
         entries[:] = [e for e in entries if e[0][0]() is not None][-3:] + [(key, res)]   # live tensors, newest four
         return res
 
@@ -431,7 +444,8 @@ def batch(graphs: Sequence[Graph]) -> Graph:
             return torch.cat([zero, torch.cat([getattr(g._s, attr)[1:] for g in graphs]) + edge_off_per_node]).to(i32)
         s.in_ptr, s.out_ptr = cat_ptr("in_ptr"), cat_ptr("out_ptr")
         s.in_src, s.out_dst, s.in_dst = (cat(a) + node_off_per_edge for a in ("in_src", "out_dst", "in_dst"))
-        s.in_eid, s.out_eid, s.out_pos = (cat(a) + edge_off_per_edge for a in ("in_eid", "out_eid", "out_pos"))
+        s.in_eid, s.out_eid, s.out_pos, s.in_pos = (cat(a) + edge_off_per_edge
+                                                    for a in ("in_eid", "out_eid", "out_pos", "in_pos"))
         s.plan_in = _cat_plans([g._s.plan_in for g in graphs], s.in_ptr, n_off, e_off, offs)
         s.plan_out = _cat_plans([g._s.plan_out for g in graphs], s.out_ptr, n_off, e_off, offs)
     out = Graph(None, _structure=s)

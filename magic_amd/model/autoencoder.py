@@ -245,7 +245,7 @@ class GMAEModel(nn.Module):
         n = g.num_nodes()
         widths = [enc[0].src_feat] + [H * D] * (len(enc) - 1) + [d.src_feat]
         masks, scale = self._dropout_masks(widths, n, g.device, drop_masks, drop_seeds)
-        return FusedCfg(g.structure.ensure_csr(), etype, enc[0].edge_feat, len(enc), H, D, d.out_feat,
+        return FusedCfg(g.structure.ensure_csr(), etype, g.edge_types_csr(), enc[0].edge_feat, len(enc), H, D, d.out_feat,
                         _pad_head_dim(d.out_feat), enc[0].leaky_relu.negative_slope, res_kinds, masks, scale)
 
     def _edge_recon(self, rows, n_pairs):

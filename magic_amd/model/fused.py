@@ -32,9 +32,11 @@ from .. import _lib, ops
 class FusedCfg:
     """Static description of one auto-encoder evaluation (built per call by GMAEModel)."""
 
-    def __init__(self, struct, etype_csc, e_dim, n_layers, n_heads, head_dim, n_dim, dec_dim_pad, slope, res_kinds,
-                 masks: List[Optional[torch.Tensor]], drop_scale: float, token_rows: Optional[torch.Tensor] = None):
-        self.struct, self.etype, self.e_dim = struct, etype_csc, e_dim
+    def __init__(self, struct, etype_csc, etype_csr, e_dim, n_layers, n_heads, head_dim, n_dim, dec_dim_pad, slope,
+                 res_kinds, masks: List[Optional[torch.Tensor]], drop_scale: float,
+                 token_rows: Optional[torch.Tensor] = None):
+        # edge types in CSC order (forward sweep) and in CSR order (backward sweeps)
+        self.struct, self.etype, self.etype_csr, self.e_dim = struct, etype_csc, etype_csr, e_dim
         self.L, self.H, self.D, self.C = n_layers, n_heads, head_dim, n_heads * head_dim
         self.n_dim, self.Dp = n_dim, dec_dim_pad
         self.slope = slope
@@ -78,22 +80,23 @@ class FusedGMAEFn(torch.autograd.Function):
             if kind == "identity":
                 res, res_mask = inp, mask
             out_l = enc[:, l * C:(l + 1) * C]
-            _, pre, attn = ops.gat_fwd(s, H, D, hs, score[:, :H], score[:, H:], table.contiguous(), cfg.etype, None,
-                                        cfg.slope, bias, res, prelu_w, True, res_mask=res_mask,
-                                        res_scale=cfg.scale, out=out_l)
-            saved += [hs, attn, pre]
+            _, pre, _, stat = ops.gat_fwd(s, H, D, hs, score[:, :H], score[:, H:], table.contiguous(), cfg.etype,
+                                          None, cfg.slope, bias, res, prelu_w, True, res_mask=res_mask,
+                                          res_scale=cfg.scale, out=out_l, want_attn=False, want_stat=True)
+            saved += [hs, score, stat, pre]
             inp = out_l
         w_e2d = params[4 * L]
         w_aug_d, table_d, bias_d = params[4 * L + 1:4 * L + 4]
         rep = ops.proj_fwd(enc, w_e2d, w_e2d.shape[0], 0, 0)[0]
         mask_d = cfg.masks[L]
         hs_d, score_d, _ = ops.proj_fwd(rep, w_aug_d, cfg.Dp, 2, 0, x_mask=mask_d, x_scale=cfg.scale)
-        recon, _, attn_d = ops.gat_fwd(s, 1, cfg.Dp, hs_d, score_d[:, :1], score_d[:, 1:], table_d.contiguous(),
-                                        cfg.etype, None, cfg.slope, bias_d, None, None, False)
+        recon, _, _, stat_d = ops.gat_fwd(s, 1, cfg.Dp, hs_d, score_d[:, :1], score_d[:, 1:], table_d.contiguous(),
+                                          cfg.etype, None, cfg.slope, bias_d, None, None, False, want_attn=False,
+                                          want_stat=True)
         samples = enc[sample_idx]
         ctx.cfg = cfg
         ctx.set_materialize_grads(False)  # no zero-filled [N, L*C] gradient for the hidden buffer
-        ctx.save_for_backward(x_in, sample_idx, enc, rep, hs_d, attn_d, *saved, *params)
+        ctx.save_for_backward(x_in, sample_idx, enc, rep, hs_d, score_d, stat_d, *saved, *params)
         ctx.mark_non_differentiable(enc)
         return enc, recon, samples
 
@@ -103,9 +106,9 @@ class FusedGMAEFn(torch.autograd.Function):
         L, H, D, C = cfg.L, cfg.H, cfg.D, cfg.C
         s = cfg.struct
         t = ctx.saved_tensors
-        x_in, sample_idx, enc, rep, hs_d, attn_d = t[:6]
-        saved = t[6:6 + 3 * L]
-        params = t[6 + 3 * L:]
+        x_in, sample_idx, enc, rep, hs_d, score_d, stat_d = t[:7]
+        saved = t[7:7 + 4 * L]
+        params = t[7 + 4 * L:]
         N = x_in.shape[0]
         dev = x_in.device
         grads = [None] * len(params)
@@ -119,8 +122,9 @@ class FusedGMAEFn(torch.autograd.Function):
             d_recon = torch.zeros(N, Dp, dtype=torch.float32, device=dev)
         d_recon = d_recon.contiguous()
         d_y = _aligned_rows(N, Dp + 2, dev)
-        d_table, _, d_bias, _ = ops.gat_bwd(s, 1, Dp, hs_d, attn_d, cfg.etype, cfg.e_dim, cfg.slope, None, None, None,
-                                             d_recon, d_recon, d_y, True)
+        table_d = params[4 * L + 2].contiguous()
+        d_table, _, d_bias, _ = ops.gat_bwd(s, 1, Dp, hs_d, score_d[:, :1], stat_d, table_d, cfg.etype_csr, None,
+                                             cfg.e_dim, cfg.slope, None, None, None, d_recon, d_recon, d_y, True)
         grads[4 * L + 1] = ops.proj_bwd_weight(d_y, rep, x_mask=mask_d, x_scale=cfg.scale)
         grads[4 * L + 2] = d_table
         grads[4 * L + 3] = d_bias
@@ -140,7 +144,8 @@ class FusedGMAEFn(torch.autograd.Function):
         off = C + 2 * H
         for l in range(L - 1, -1, -1):
             w_aug, table, bias, prelu_w = params[4 * l:4 * l + 4]
-            hs, attn, pre = saved[3 * l:3 * l + 3]
+            hs, score, stat, pre = saved[4 * l:4 * l + 4]
+            table = table.contiguous()
             kind = cfg.res_kinds[l]
             mask = cfg.masks[l]
             inp = x_in if l == 0 else enc[:, (l - 1) * C:l * C]
@@ -150,12 +155,12 @@ class FusedGMAEFn(torch.autograd.Function):
                 d_y = _aligned_rows(N, w_aug.shape[0], dev)
                 d_pre = d_y[:, off:] if kind == "linear" else torch.empty(N, C, dtype=torch.float32, device=dev)
                 d_table, _, bias_grad, prelu_grad = ops.gat_bwd(
-                    s, H, D, hs, attn, cfg.etype, cfg.e_dim, cfg.slope, pre, enc[:, l * C:(l + 1) * C], prelu_w,
-                    d_enc[:, l * C:(l + 1) * C], d_pre, d_y, True)
+                    s, H, D, hs, score[:, :H], stat, table, cfg.etype_csr, None, cfg.e_dim, cfg.slope, pre,
+                    enc[:, l * C:(l + 1) * C], prelu_w, d_enc[:, l * C:(l + 1) * C], d_pre, d_y, True)
             else:
                 d_y = d_y_next if d_y_next is not None else _aligned_rows(N, w_aug.shape[0], dev)
-                d_table = ops.gat_bwd(s, H, D, hs, attn, cfg.etype, cfg.e_dim, cfg.slope, None, None, None,
-                                       d_pre, d_pre, d_y, False)[0]
+                d_table = ops.gat_bwd(s, H, D, hs, score[:, :H], stat, table, cfg.etype_csr, None, cfg.e_dim,
+                                       cfg.slope, None, None, None, d_pre, d_pre, d_y, False)[0]
             token_path = (l == 0 and cfg.token_rows is not None and ctx.needs_input_grad[3]
                           and not ctx.needs_input_grad[0] and kind != "identity")
             if not token_path:  # (the token path below produces this layer's weight gradient itself)
@@ -172,7 +177,7 @@ class FusedGMAEFn(torch.autograd.Function):
                     target = d_y_next[:, off:]
                 d_pre, bias_grad, prelu_grad = ops.proj_bwd_input(
                     d_y, w_aug, add=add, out_mask=mask, out_scale=cfg.scale, add2=d_enc[:, (l - 1) * C:l * C],
-                    act_out=inp, act_pre=saved[3 * (l - 1) + 2], prelu_w=params[4 * (l - 1) + 3],
+                    act_out=inp, act_pre=saved[4 * (l - 1) + 3], prelu_w=params[4 * (l - 1) + 3],
                     want_col_sum=True, out=target)
             else:
                 want_token = cfg.token_rows is not None and ctx.needs_input_grad[3]

@@ -87,17 +87,22 @@ class _GATLayerFn(torch.autograd.Function):
             table, ee_csc = edge_term.contiguous(), None
         else:
             table, ee_csc = None, edge_term[struct.in_eid.long()].contiguous()
-        want_pre = prelu_w is not None and cfg["need_grad"]
-        out, pre, attn = ops.gat_fwd(struct, H, Dp, hs, score[:, :H], score[:, H:], table, etype, ee_csc,
-                                      cfg["slope"], bias, res, prelu_w, want_pre)
+        need_grad = cfg["need_grad"]
+        want_pre = prelu_w is not None and need_grad
+        out, pre, attn, stat = ops.gat_fwd(struct, H, Dp, hs, score[:, :H], score[:, H:], table, etype, ee_csc,
+                                            cfg["slope"], bias, res, prelu_w, want_pre, want_attn=cfg["want_attn"],
+                                            want_stat=need_grad)
         ctx.struct, ctx.cfg = struct, cfg
-        ctx.save_for_backward(h, w_aug, hs, attn, pre, prelu_w, out if prelu_w is not None else None)
+        ctx.save_for_backward(h, w_aug, hs, score, stat, table, ee_csc, pre, prelu_w,
+                              out if prelu_w is not None else None)
+        if attn is None:
+            attn = hs.new_empty(0)
         ctx.mark_non_differentiable(attn)
         return out, attn
 
     @staticmethod
     def backward(ctx, d_out, _d_attn):
-        h, w_aug, hs, attn, pre, prelu_w, act_out = ctx.saved_tensors
+        h, w_aug, hs, score, stat, table, ee_csc, pre, prelu_w, act_out = ctx.saved_tensors
         struct, cfg = ctx.struct, ctx.cfg
         H, Dp, C, res_c = cfg["H"], cfg["Dp"], cfg["C"], cfg["res_c"]
         N = h.shape[0]
@@ -108,10 +113,10 @@ class _GATLayerFn(torch.autograd.Function):
             d_pre = d_y[:, C + 2 * H:]
         else:
             d_pre = torch.empty(N, C, dtype=torch.float32, device=h.device)
-        etype = cfg["etype_csc"]
+        dense = table is None
         d_table, rec, d_bias, d_prelu = ops.gat_bwd(
-            struct, H, Dp, hs, attn, etype, cfg["e_dim"], cfg["slope"], pre, act_out, prelu_w, d_out, d_pre, d_y,
-            cfg["has_bias"])
+            struct, H, Dp, hs, score[:, :H], stat, table, cfg["etype_csr"], ee_csc, cfg["e_dim"], cfg["slope"], pre,
+            act_out, prelu_w, d_out, d_pre, d_y, cfg["has_bias"], want_dlogit=dense and ctx.needs_input_grad[2])
         if res_c and d_pre.data_ptr() != d_y[:, C + 2 * H:].data_ptr():
             d_y[:, C + 2 * H:] = d_pre
         d_h = d_w = d_edge = None
@@ -120,11 +125,12 @@ class _GATLayerFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             d_w = ops.proj_bwd_weight(d_y, h)
         if ctx.needs_input_grad[2]:
-            if etype is not None:
+            if not dense:
                 d_edge = d_table
             else:
                 d_edge = torch.empty(struct.num_edges, H, dtype=torch.float32, device=h.device)
-                d_edge[struct.in_eid.long()] = rec
+                if struct.num_edges:
+                    d_edge[struct.in_eid.long()] = rec
         return d_h, d_w, d_edge, d_bias, d_prelu, None, None
 
 
@@ -271,8 +277,10 @@ class GATConv(nn.Module):
         prelu_w = self.activation.weight if fuse_act else None
         need_grad = torch.is_grad_enabled()
         cfg = dict(H=H, Dp=Dp, C=C, res_c=C if isinstance(self.res_fc, nn.Linear) else 0,
-                   res_identity=res_identity, etype_csc=etype_csc, e_dim=self.edge_feat,
-                   slope=self.leaky_relu.negative_slope, has_bias=bias is not None, need_grad=need_grad)
+                   res_identity=res_identity, etype_csc=etype_csc,
+                   etype_csr=graph.edge_types_csr() if need_grad else None, e_dim=self.edge_feat,
+                   slope=self.leaky_relu.negative_slope, has_bias=bias is not None, need_grad=need_grad,
+                   want_attn=bool(get_attention))
         out, attn = _GATLayerFn.apply(h, w_aug, edge_term, bias, prelu_w, struct, cfg)
         rst = out
         if Dp != D:

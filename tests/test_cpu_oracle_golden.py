@@ -419,10 +419,15 @@ def test_custom_ops_are_registered_with_schemas_and_fake_kernels():
         plan = [torch.empty(n + 1, **i32)] + [torch.empty(0, **i32) for _ in range(5)] + [torch.empty(n, **i32)]
         f = lambda *s: torch.empty(*s, device=dev)   # noqa: E731
         out = f(n, h * d)
-        pre, attn = torch.ops.magic.gat_fwd_(*plan, torch.empty(e, **i32), torch.empty(e, **i32), h, d, f(n, h * d),
-                                             f(n, h), f(n, h), f(17, h), torch.empty(e, **i32), None, 0.2, f(h * d),
-                                             None, f(1), True, None, 1.0, out)
-        assert pre.shape == (n, h * d) and attn.shape == (e, h)
+        pre, attn, stat = torch.ops.magic.gat_fwd_(*plan, torch.empty(e, **i32), torch.empty(e, **i32), h, d,
+                                                   f(n, h * d), f(n, h), f(n, h), f(17, h), torch.empty(e, **i32),
+                                                   None, 0.2, f(h * d), None, f(1), True, None, 1.0, True, True, out)
+        assert pre.shape == (n, h * d) and attn.shape == (e, h) and stat.shape == (n, h, 2)
+        d_table, d_logit, d_bias, d_prelu = torch.ops.magic.gat_bwd_(
+            *plan, *plan, torch.empty(e, **i32), torch.empty(e, **i32), torch.empty(e, **i32), h, d, f(n, h * d),
+            f(n, h), stat, f(17, h), torch.empty(e, **i32), None, 17, 0.2, None, None, None, f(n, h * d), f(n, h * d),
+            f(n, h * d + 2 * h), True, False)
+        assert d_table.shape == (17, h) and d_logit.numel() == 0 and d_bias.shape == (h * d,) and d_prelu.numel() == 0
         ptrs = torch.ops.magic.csr_build(torch.empty(e, dtype=torch.int64, device=dev),
                                          torch.empty(e, dtype=torch.int64, device=dev), n)
         assert ptrs[0].shape == (n + 1,) and ptrs[1].dtype == torch.int32 and ptrs[5].shape == (e,)

@@ -48,7 +48,7 @@ def test_batch_csr_equals_direct_sort(cuda):
         gs.append(g)
     bg = batch(gs)
     direct = Structure(bg.edges()[0], bg.edges()[1], bg.num_nodes()).ensure_csr()
-    for name in ("in_ptr", "in_src", "in_eid", "in_dst", "out_ptr", "out_dst", "out_eid", "out_pos"):
+    for name in ("in_ptr", "in_src", "in_eid", "in_dst", "out_ptr", "out_dst", "out_eid", "out_pos", "in_pos"):
         assert torch.equal(getattr(bg.structure, name), getattr(direct, name)), name
     # the union's segment plans, assembled from the components' plans, equal the ones built from scratch
     for which in ("plan_in", "plan_out"):

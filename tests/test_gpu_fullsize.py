@@ -45,6 +45,7 @@ def test_csr_invariants_full_size(theia):
         assert torch.equal(torch.bincount(key, minlength=n), (ptr[1:] - ptr[:-1]).long())
     assert torch.equal(s.in_src.long(), src[s.in_eid.long()])
     assert torch.equal(s.in_eid.long()[s.out_pos.long()], s.out_eid.long())              # CSR slot -> CSC slot
+    assert torch.equal(s.out_eid.long()[s.in_pos.long()], s.in_eid.long())               # CSC slot -> CSR slot
 
 
 def test_attention_rows_sum_to_one_and_isolated_nodes(theia, cuda):
@@ -154,7 +155,7 @@ def test_streamspot_batch_step_reproducible_and_directional_derivative(cuda):
     n, e = g.num_nodes(), g.num_edges()
     assert (n, e) == (12 * n1, sum(p.num_edges() for p in parts))
     direct = Structure(g.edges()[0], g.edges()[1], n).ensure_csr()
-    for name in ("in_ptr", "in_src", "in_eid", "out_ptr", "out_dst", "out_eid", "out_pos"):
+    for name in ("in_ptr", "in_src", "in_eid", "out_ptr", "out_dst", "out_eid", "out_pos", "in_pos"):
         assert torch.equal(getattr(g.structure, name), getattr(direct, name)), name
     g.edata["attr"] = torch.nn.functional.one_hot(g.edata["type"], e_dim).float()
     torch.manual_seed(0)

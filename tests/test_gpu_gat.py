@@ -360,15 +360,28 @@ def test_custom_operators_called_directly(cuda):
     table = torch.randn(e_dim, H, device=cuda)
     bias = torch.randn(H * D, device=cuda)
     out = torch.empty(n, H * D, device=cuda)
-    pre, attn = torch.ops.magic.gat_fwd_(*ops.plan_tensors(s.plan_in), s.in_src, s.in_dst, H, D, hs, eh, et, table,
-                                         g.edge_types_csc(), None, 0.2, bias, None, None, False, None, 1.0, out)
-    assert pre.numel() == 0 and attn.shape == (src.size, H)
+    pre, attn, stat = torch.ops.magic.gat_fwd_(*ops.plan_tensors(s.plan_in), s.in_src, s.in_dst, H, D, hs, eh, et,
+                                               table, g.edge_types_csc(), None, 0.2, bias, None, None, False, None,
+                                               1.0, True, True, out)
+    assert pre.numel() == 0 and attn.shape == (src.size, H) and stat.shape == (n, H, 2)
     # oracle statement of model/gat.py:302-324 on the same operands
     S, T = torch.from_numpy(src), torch.from_numpy(dst)
     x = (eh.cpu().double()[S] + table.cpu().double()[torch.from_numpy(etype)]) + et.cpu().double()[T]
-    a = O.edge_softmax(T, torch.nn.functional.leaky_relu(x, 0.2).unsqueeze(-1), n)
+    lx = torch.nn.functional.leaky_relu(x, 0.2)
+    a = O.edge_softmax(T, lx.unsqueeze(-1), n)
     want = O.u_mul_e_sum(S, T, hs.cpu().double().view(n, H, D), a, n).reshape(n, H * D) + bias.cpu().double()
     assert rel_err(out, want) < 1e-5
+    # attention weights (CSC order, sign bit = logit not positive) and the per-destination statistics
+    eid = s.in_eid.long().cpu()
+    assert (attn.cpu().abs().double() - a.squeeze(-1)[eid]).abs().max() < 1e-6
+    assert torch.equal(attn.cpu() < 0, (x[eid] <= 0) & (attn.cpu() != 0))
+    has_in = torch.zeros(n, dtype=torch.bool).index_fill_(0, T, True)
+    lse = torch.full((n, H), -float("inf"), dtype=torch.float64)
+    lse = lse.scatter_reduce(0, T.view(-1, 1).expand(-1, H), lx, "amax")
+    lse = lse + torch.log(torch.zeros(n, H, dtype=torch.float64).index_add_(0, T, torch.exp(lx - lse[T])))
+    assert torch.equal(stat[:, :, 0].cpu(), et.cpu())
+    assert (stat[:, :, 1].cpu().double() - lse)[has_in].abs().max() < 1e-5
+    assert (stat[:, :, 1].cpu()[~has_in] == 0).all()
     # differentiable operators
     xw = torch.randn(300, 24, device=cuda, requires_grad=True)
     w = torch.randn(40, 24, device=cuda, requires_grad=True)
