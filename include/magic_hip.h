@@ -86,9 +86,15 @@ typedef struct magic_plan {
     const int32_t *chunk_node; /* [n_chunks] heavy slot (index into heavy_node) */
     const int32_t *chunk_beg;  /* [n_chunks] first edge of the chunk */
     const int32_t *chunk_end;  /* [n_chunks] one past the last edge */
-    const int32_t *node_order; /* [N] node ids by ascending segment-length class (stable), or NULL for 0..N-1:
-                                  the node-driven kernels walk nodes in this order so that the lane groups
-                                  of one wavefront hold segments of equal length (results do not depend on it) */
+    const int32_t *node_order; /* [N] walk order of the node-driven kernels, or NULL for 0..N-1: node ids
+                                  sorted by (XCD range, segment-length class), stable, so that the lane
+                                  groups of one wavefront hold segments of equal length (results do not
+                                  depend on it) */
+    const int32_t *xcd_start;  /* [9] or NULL: positions that cut node_order (and, being monotone in the
+                                  node id, the id range 0..N-1 as well) into 8 contiguous ranges of equal
+                                  work (edges + 2 per node).  Workgroups b, b+8, b+16, ... share one XCD and
+                                  its L2; they walk range b % 8, so an XCD's gathers stay inside the rows
+                                  its own node range touches (whole component graphs of a batch) */
 } magic_plan;
 
 /* ------------------------------------------------------------------------------------

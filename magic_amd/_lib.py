@@ -23,7 +23,7 @@ c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C
 class MagicPlan(C.Structure):
     _fields_ = [("ptr", c_vp), ("light_max", c_i32), ("n_heavy", c_i32), ("heavy_node", c_vp),
                 ("heavy_cptr", c_vp), ("n_chunks", c_i32), ("chunk_node", c_vp), ("chunk_beg", c_vp),
-                ("chunk_end", c_vp), ("node_order", c_vp)]
+                ("chunk_end", c_vp), ("node_order", c_vp), ("xcd_start", c_vp)]
 
 
 # name -> (restype, argtypes); must list every symbol include/magic_hip.h declares
@@ -190,6 +190,8 @@ def make_plan(plan, light_max: int) -> MagicPlan:
     p.chunk_beg = plan.chunk_beg.data_ptr() if plan.n_chunks else None
     p.chunk_end = plan.chunk_end.data_ptr() if plan.n_chunks else None
     p.node_order = plan.order.data_ptr() if plan.order is not None else None
+    xs = getattr(plan, "xcd_start", None)
+    p.xcd_start = xs.data_ptr() if xs is not None and p.node_order is not None else None
     return p
 
 

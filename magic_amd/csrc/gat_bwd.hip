@@ -175,19 +175,20 @@ template <int H, int LPH, bool TABLE>
 __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
     constexpr int G = H * LPH;
     constexpr int NPB = 256 / G;
-    constexpr int SB = 4;  // edges per batch
+    constexpr int SB = 4;  // edges per batch (8 for wide rows: fewer resident waves, slower)
     __shared__ float tbl[TABLE ? MAX_E_DIM * H : 1];
     stage_table<H, TABLE>(a, tbl);
     const int g = threadIdx.x % G;
     const int h = g / LPH;
     const bool writer = (g % LPH) == 0;
     const int slot = threadIdx.x / G;
-    const int stride = gridDim.x * NPB;
+    const Walk wk = xcd_walk(a.pout, a.N, NPB, slot);
+    const int stride = wk.stride;
     const bool ordered = G >= 8 && a.pout.order != nullptr;
-    const int last_node = a.N - 1;
-    int i0 = blockIdx.x * NPB + slot;  // walk index of the current node
+    const int last_pos = max(wk.end - 1, 0);
+    int i0 = wk.pos;  // walk index of the current node
     auto node_at = [&](int i) {
-        i = min(i, last_node);
+        i = min(i, last_pos);
         return ordered ? a.pout.order[i] : i;
     };
     // edge slot of batch element k (clamped into the segment; into the edge array for empty segments)
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
     float4 hu = ld4_nt(a.hs + (int64_t)u0 * a.ld_hs + g * 4);
     float ehu = a.eh[(int64_t)u0 * a.ld_s + h];
     float4 acc = f4zero();
-    while (i0 < a.N) {
+    while (i0 < wk.end) {
         const bool light = e0 - b0 <= a.pout.light_max;
         const bool last = !light || j + SB >= e0;  // this batch ends the node
         // 1. gathers of the current batch
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void k_bwd_src_heavy1(BwdArgs a) {
     __shared__ float tbl[TABLE ? MAX_E_DIM * H : 1];
     stage_table<H, TABLE>(a, tbl);
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = xcd_chunk(threadIdx.x >> 6);
     if (c >= a.pout.n_chunks) return;
     const int u = a.pout.heavy_node[a.pout.chunk_node[c]];
     const int beg = a.pout.chunk_beg[c], end = a.pout.chunk_end[c];
@@ -407,7 +408,8 @@ template <int H>
 __global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a, int C) {
     constexpr int W = DST_W, NPB = 256 / W;
     const int q = threadIdx.x % W, slot = threadIdx.x / W;
-    for (int vi = blockIdx.x * NPB + slot; vi < a.N; vi += gridDim.x * NPB) {
+    const Walk wk = xcd_walk(a.pin, a.N, NPB, slot);
+    for (int vi = wk.pos; vi < wk.end; vi += wk.stride) {
         const int v = a.pin.order ? a.pin.order[vi] : vi;
         const int b = a.pin.ptr[v], e = a.pin.ptr[v + 1];
         if (e - b > a.pin.light_max) continue;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a, int C) {
 template <int H>
 __global__ __launch_bounds__(256) void k_bwd_dst_heavy1(BwdArgs a) {
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = xcd_chunk(threadIdx.x >> 6);
     if (c >= a.pin.n_chunks) return;
     const int beg = a.pin.chunk_beg[c], end = a.pin.chunk_end[c];
     DstSums<H> s;
@@ -512,7 +514,8 @@ template <int H>
 __global__ __launch_bounds__(256) void k_bwd_deh_light(BwdArgs a, int C) {
     constexpr int W = DEH_W, NPB = 256 / W;
     const int q = threadIdx.x % W, slot = threadIdx.x / W;
-    for (int ui = blockIdx.x * NPB + slot; ui < a.N; ui += gridDim.x * NPB) {
+    const Walk wk = xcd_walk(a.pout, a.N, NPB, slot);  // the ranges cut the node ids at the same positions
+    for (int ui = wk.pos; ui < wk.end; ui += wk.stride) {
         const int u = ui;  // natural order: neighbouring groups stream neighbouring segments
         const int b = a.pout.ptr[u], e = a.pout.ptr[u + 1];
         if (e - b > a.pout.light_max) continue;
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(256) void k_bwd_deh_light(BwdArgs a, int C) {
 template <int H>
 __global__ __launch_bounds__(256) void k_bwd_deh_heavy1(BwdArgs a) {
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = xcd_chunk(threadIdx.x >> 6);
     if (c >= a.pout.n_chunks) return;
     const int beg = a.pout.chunk_beg[c], end = a.pout.chunk_end[c];
     float s[H];
@@ -675,19 +678,19 @@ int launch_bwd(BwdArgs &a, hipStream_t stream) {
     }
     MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_light<H, LPH, TABLE>), stride_grid(a.N, NPB, 256 * 16), 256, 0, stream, a);
     if (a.pout.n_chunks > 0) {
-        const int cgrid = (a.pout.n_chunks + 3) / 4;
+        const int cgrid = chunk_grid(a.pout.n_chunks);
         MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_heavy1", H, LPH) : "gat_bwd_src_heavy1", (k_bwd_src_heavy1<H, LPH, TABLE>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_bwd_src_heavy2", (k_bwd_src_heavy2<H, LPH>), a.pout.n_heavy, 256, 0, stream, a);
     }
     MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_dst_light", H, LPH) : "gat_bwd_dst_light", (k_bwd_dst_light<H>), stride_grid(a.N, 256 / DST_W, 256 * 32), 256, 0, stream, a, C);
     if (a.pin.n_chunks > 0) {
-        const int cgrid = (a.pin.n_chunks + 3) / 4;
+        const int cgrid = chunk_grid(a.pin.n_chunks);
         MAGIC_LAUNCH("gat_bwd_dst_heavy1", (k_bwd_dst_heavy1<H>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_bwd_dst_heavy2", (k_bwd_dst_heavy2<H>), (a.pin.n_heavy + 3) / 4, 256, 0, stream, a, C);
     }
     MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_deh_light", H, LPH) : "gat_bwd_deh_light", (k_bwd_deh_light<H>), stride_grid(a.N, 256 / DEH_W, 256 * 32), 256, 0, stream, a, C);
     if (a.pout.n_chunks > 0) {
-        MAGIC_LAUNCH("gat_bwd_deh_heavy1", (k_bwd_deh_heavy1<H>), (a.pout.n_chunks + 3) / 4, 256, 0, stream, a);
+        MAGIC_LAUNCH("gat_bwd_deh_heavy1", (k_bwd_deh_heavy1<H>), chunk_grid(a.pout.n_chunks), 256, 0, stream, a);
         MAGIC_LAUNCH("gat_bwd_deh_heavy2", (k_bwd_deh_heavy2<H>), (a.pout.n_heavy + 3) / 4, 256, 0, stream, a, C);
     }
     int st = launch_table<H, LPH>(a, stream);

@@ -20,7 +20,8 @@ struct PlanDev {
     const int32_t *chunk_node;
     const int32_t *chunk_beg;
     const int32_t *chunk_end;
-    const int32_t *order;  // node walk order, or null
+    const int32_t *order;      // node walk order, or null
+    const int32_t *xcd_start;  // [9] cuts of the walk into 8 ranges, or null
 };
 
 inline PlanDev plan_dev(const magic_plan *p) {
@@ -35,6 +36,7 @@ inline PlanDev plan_dev(const magic_plan *p) {
     d.chunk_beg = p->chunk_beg;
     d.chunk_end = p->chunk_end;
     d.order = p->node_order;
+    d.xcd_start = p->xcd_start;
     return d;
 }
 
@@ -45,6 +47,36 @@ inline bool plan_valid(const magic_plan *p) {
     if ((p->n_heavy == 0) != (p->n_chunks == 0)) return false;
     return true;
 }
+
+// ---- XCD-aware work distribution --------------------------------------------------------------
+// Workgroups are dealt round robin over the 8 XCDs (b and b + 8 share one L2).  A node-driven kernel
+// gives XCD range x = b % 8 of the walk to the workgroups b = x, x + 8, ...; `per_block` walk positions
+// per workgroup and trip.
+struct Walk {
+    int pos, end, stride;
+};
+__device__ __forceinline__ Walk xcd_walk(const PlanDev &p, int N, int per_block, int slot) {
+    Walk w;
+    if (p.xcd_start == nullptr || gridDim.x < 8) {
+        w.pos = blockIdx.x * per_block + slot;
+        w.end = N;
+        w.stride = gridDim.x * per_block;
+    } else {
+        const int x = blockIdx.x & 7, lb = blockIdx.x >> 3;
+        const int nlb = (gridDim.x - x + 7) >> 3;  // workgroups that share this range
+        w.pos = p.xcd_start[x] + lb * per_block + slot;
+        w.end = p.xcd_start[x + 1];
+        w.stride = nlb * per_block;
+    }
+    return w;
+}
+// Chunk of wave `wave` (0..3) of this workgroup in a one-wave-per-chunk kernel whose grid is a multiple
+// of 8 workgroups (chunk_grid): every XCD takes a contiguous run of chunks, i.e. of heavy nodes.
+__device__ __forceinline__ int xcd_chunk(int wave) {
+    const int per = (gridDim.x >> 3) * 4;
+    return (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + wave;
+}
+inline int chunk_grid(int n_chunks) { return ((n_chunks + 3) / 4 + 7) / 8 * 8; }
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }

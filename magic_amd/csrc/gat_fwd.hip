@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
     const int q = g % LPH;
     const int slot = threadIdx.x / G;
     const bool writer = q == 0;
-    for (int vi = blockIdx.x * NPB + slot; vi < a.N; vi += gridDim.x * NPB) {
+    const Walk wk = xcd_walk(a.plan, a.N, NPB, slot);
+    for (int vi = wk.pos; vi < wk.end; vi += wk.stride) {
         // walk nodes by segment length when a node row is wide enough to stand alone in memory
         const int v = (G >= 8 && a.plan.order) ? a.plan.order[vi] : vi;
         const int b = a.plan.ptr[v], e = a.plan.ptr[v + 1];
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
 template <int H>
 __global__ __launch_bounds__(256) void k_fwd_heavy_stats(FwdArgs a) {
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = xcd_chunk(threadIdx.x >> 6);
     if (c >= a.plan.n_chunks) return;
     const int beg = a.plan.chunk_beg[c], end = a.plan.chunk_end[c];
     float m[H], s[H];
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
     constexpr int NSG = 64 / G;
     constexpr int C = G * 4;
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = xcd_chunk(threadIdx.x >> 6);
     if (c >= a.plan.n_chunks) return;
     const int slot = a.plan.chunk_node[c];
     const int beg = a.plan.chunk_beg[c], end = a.plan.chunk_end[c];
@@ -339,7 +340,7 @@ int launch_fwd(const FwdArgs &a, bool table, hipStream_t stream) {
         MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_light", H, LPH) : "gat_fwd_light", (k_fwd_light<H, LPH>), grid, 256, 0, stream, a);
     }
     if (a.plan.n_chunks > 0) {
-        int cgrid = (a.plan.n_chunks + 3) / 4;
+        int cgrid = chunk_grid(a.plan.n_chunks);
         MAGIC_LAUNCH("gat_fwd_heavy_stats", (k_fwd_heavy_stats<H>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_heavy_agg", H, LPH) : "gat_fwd_heavy_agg", (k_fwd_heavy_agg<H, LPH>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_fwd_heavy_finish", (k_fwd_heavy_finish<H, LPH>), a.plan.n_heavy, 256, 0, stream, a);

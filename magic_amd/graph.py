@@ -45,14 +45,16 @@ class SegmentPlan:
     ``heavy_cptr`` int32 [nh+1]  first chunk of each heavy node
     ``chunk_node`` int32 [nc]    heavy-node slot (index into heavy_node) of each chunk
     ``chunk_beg`` / ``chunk_end`` int32 [nc]  edge range of each chunk
-    ``order``      int32 [N]     node ids by ascending segment-length class (``walk_class``, stable):
-                                 the walk order of the node-driven kernels
+    ``order``      int32 [N]     walk order of the node-driven kernels: node ids sorted by (XCD range,
+                                 segment-length class ``walk_class``), stable
+    ``xcd_start``  int32 [9]     cuts of ``order`` (equally: of the node ids) into 8 ranges of equal work;
+                                 the workgroups that share an XCD's L2 walk one range (``walk_order``)
     """
 
     __slots__ = ("ptr", "heavy_node", "heavy_cptr", "chunk_node", "chunk_beg", "chunk_end",
-                 "n_heavy", "n_chunks", "order")
+                 "n_heavy", "n_chunks", "order", "xcd_start")
 
-    def __init__(self, ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end, order=None):
+    def __init__(self, ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end, order=None, xcd_start=None):
         self.ptr = ptr
         self.heavy_node = heavy_node
         self.heavy_cptr = heavy_cptr
@@ -62,11 +64,13 @@ class SegmentPlan:
         self.n_heavy = int(heavy_node.numel())
         self.n_chunks = int(chunk_node.numel())
         self.order = order
+        self.xcd_start = xcd_start
 
     def to(self, device):
         return SegmentPlan(*(t.to(device) for t in (self.ptr, self.heavy_node, self.heavy_cptr,
                                                      self.chunk_node, self.chunk_beg, self.chunk_end)),
-                           order=None if self.order is None else self.order.to(device))
+                           order=None if self.order is None else self.order.to(device),
+                           xcd_start=None if self.xcd_start is None else self.xcd_start.to(device))
 
 
 def walk_class(deg: torch.Tensor) -> torch.Tensor:
@@ -78,6 +82,28 @@ def walk_class(deg: torch.Tensor) -> torch.Tensor:
     return torch.where(deg <= 0, torch.zeros_like(deg),
                        torch.where(deg <= 4, torch.ones_like(deg),
                                    torch.ceil(torch.log2(d.clamp(min=1))).to(deg.dtype)))
+
+
+N_XCD = 8
+
+
+def walk_order(ptr: torch.Tensor, light_max: int = LIGHT_MAX):
+    """(order [N], xcd_start [9]) of a segment array.  The node ids 0..N-1 are cut into 8 contiguous
+    ranges of equal node-driven work (per node: its edges when the segment is light -- heavy segments
+    are spread chunk by chunk, separately -- plus 2 for its own row traffic); inside a range nodes go
+    by ascending segment-length class.  The workgroups that share one XCD (and its 4 MB L2) walk one
+    range, so what they gather stays inside the rows that range's edges reach -- for a batch of
+    component graphs, the rows of one or two components.  No host round trip."""
+    ptr64 = ptr.to(torch.int64)
+    n = ptr64.numel() - 1
+    deg = ptr64[1:] - ptr64[:-1]
+    cost = torch.where(deg <= light_max, deg, torch.zeros_like(deg)) + 2
+    work = torch.cumsum(cost, 0) - cost                                      # work before each node
+    total = cost.sum().clamp(min=1)
+    xcd = ((work * N_XCD) // total).clamp(max=N_XCD - 1)                     # non-decreasing in the node id
+    order = torch.sort(xcd * 64 + walk_class(deg), stable=True).indices.to(torch.int32)
+    xcd_start = torch.searchsorted(xcd, torch.arange(N_XCD + 1, dtype=torch.int64, device=ptr.device)).to(torch.int32)
+    return order, xcd_start
 
 
 def build_segment_plan(ptr: torch.Tensor, light_max: int = LIGHT_MAX, chunk: int = CHUNK) -> SegmentPlan:
@@ -100,9 +126,9 @@ def build_segment_plan(ptr: torch.Tensor, light_max: int = LIGHT_MAX, chunk: int
     beg = ptr64[heavy_node][slot] + within * chunk if nc else slot
     end = torch.minimum(beg + chunk, ptr64[heavy_node + 1][slot]) if nc else slot
     i32 = torch.int32
-    order = torch.sort(walk_class(deg), stable=True).indices.to(i32)
+    order, xcd_start = walk_order(ptr)
     return SegmentPlan(ptr.to(i32).contiguous(), heavy_node.to(i32), heavy_cptr.to(i32),
-                       slot.to(i32), beg.to(i32), end.to(i32), order=order)
+                       slot.to(i32), beg.to(i32), end.to(i32), order=order, xcd_start=xcd_start)
 
 
 class Structure:
@@ -401,10 +427,9 @@ def _cat_plans(plans, ptr, n_off, e_off, offs: _Offsets) -> SegmentPlan:
     else:
         heavy_node = chunk_node = chunk_beg = chunk_end = torch.zeros(0, dtype=i32, device=dev)
         heavy_cptr = torch.zeros(1, dtype=i32, device=dev)
-    deg = (ptr[1:] - ptr[:-1]).to(torch.int64)
-    order = torch.sort(walk_class(deg), stable=True).indices.to(i32)
+    order, xcd_start = walk_order(ptr)
     return SegmentPlan(ptr, heavy_node.to(i32), heavy_cptr.to(i32), chunk_node.to(i32), chunk_beg.to(i32),
-                       chunk_end.to(i32), order=order)
+                       chunk_end.to(i32), order=order, xcd_start=xcd_start)
 
 
 def batch(graphs: Sequence[Graph]) -> Graph:

@@ -12,8 +12,8 @@ Differentiable entry points built on them live next to the reference-shaped modu
 autograd formula so that they can be used on their own: ``magic::sce_loss`` and
 ``magic::linear_nobias``.
 
-The segment plan of a graph direction (``graph.SegmentPlan``) travels as seven int32 tensors:
-``ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end, order``.
+The segment plan of a graph direction (``graph.SegmentPlan``) travels as eight int32 tensors:
+``ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end, order, xcd_start``.
 """
 from __future__ import annotations
 
@@ -27,7 +27,7 @@ from . import _lib
 
 _L = torch.library.Library("magic", "DEF")
 _PLAN = "Tensor {0}ptr, Tensor {0}heavy_node, Tensor {0}heavy_cptr, Tensor {0}chunk_node, Tensor {0}chunk_beg, " \
-        "Tensor {0}chunk_end, Tensor {0}order"
+        "Tensor {0}chunk_end, Tensor {0}order, Tensor {0}xcd_start"
 
 
 def _register(name: str, schema: str, impl, fake):
@@ -44,16 +44,19 @@ def _empty(like: Tensor, dtype=torch.float32) -> Tensor:
     return torch.empty(0, dtype=dtype, device=like.device)
 
 
-def _plan(ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end, order):
+def _plan(ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end, order, xcd_start):
     from .graph import SegmentPlan
     return SegmentPlan(ptr, heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end,
-                       order=order if order.numel() else None)
+                       order=order if order.numel() else None, xcd_start=xcd_start if xcd_start.numel() else None)
 
 
 def plan_tensors(plan) -> List[Tensor]:
-    """The seven tensors of a ``graph.SegmentPlan`` in operator-argument order."""
-    order = plan.order if plan.order is not None else torch.empty(0, dtype=torch.int32, device=plan.ptr.device)
-    return [plan.ptr, plan.heavy_node, plan.heavy_cptr, plan.chunk_node, plan.chunk_beg, plan.chunk_end, order]
+    """The eight tensors of a ``graph.SegmentPlan`` in operator-argument order."""
+    none = torch.empty(0, dtype=torch.int32, device=plan.ptr.device)
+    order = plan.order if plan.order is not None else none
+    xcd_start = plan.xcd_start if plan.xcd_start is not None else none
+    return [plan.ptr, plan.heavy_node, plan.heavy_cptr, plan.chunk_node, plan.chunk_beg, plan.chunk_end, order,
+            xcd_start]
 
 
 # ------------------------------------------------------------------------------------- csr_build
@@ -132,10 +135,10 @@ def _struct_in(n_nodes, plan7, in_src, in_dst):
                            in_dst=in_dst)
 
 
-def _gat_fwd_(p0, p1, p2, p3, p4, p5, p6, in_src, in_dst, n_heads: int, head_dim: int, hs, eh, et, ee_table,
+def _gat_fwd_(p0, p1, p2, p3, p4, p5, p6, p7, in_src, in_dst, n_heads: int, head_dim: int, hs, eh, et, ee_table,
               etype_csc, ee_csc, slope: float, bias, res, prelu_w, want_pre: bool, res_mask, res_scale: float,
               want_attn: bool, want_stat: bool, out):
-    s = _struct_in(out.shape[0], (p0, p1, p2, p3, p4, p5, p6), in_src, in_dst)
+    s = _struct_in(out.shape[0], (p0, p1, p2, p3, p4, p5, p6, p7), in_src, in_dst)
     _, pre, attn, stat = _lib.gat_fwd(s, n_heads, head_dim, hs, eh, et, ee_table, etype_csc, ee_csc, slope, bias, res,
                                       prelu_w, want_pre, res_mask=res_mask, res_scale=res_scale, out=out,
                                       want_attn=want_attn, want_stat=want_stat)
@@ -143,7 +146,7 @@ def _gat_fwd_(p0, p1, p2, p3, p4, p5, p6, in_src, in_dst, n_heads: int, head_dim
     return pre if pre is not None else e, attn if attn is not None else e, stat if stat is not None else e
 
 
-def _gat_fwd__fake(p0, p1, p2, p3, p4, p5, p6, in_src, in_dst, n_heads, head_dim, hs, eh, et, ee_table, etype_csc,
+def _gat_fwd__fake(p0, p1, p2, p3, p4, p5, p6, p7, in_src, in_dst, n_heads, head_dim, hs, eh, et, ee_table, etype_csc,
                    ee_csc, slope, bias, res, prelu_w, want_pre, res_mask, res_scale, want_attn, want_stat, out):
     n, c = out.shape[0], n_heads * head_dim
     return (hs.new_empty((n, c) if want_pre else (0,)),
@@ -157,11 +160,11 @@ _register("gat_fwd_", "(" + _PLAN.format("in_") + ", Tensor in_src, Tensor in_ds
           "bool want_attn, bool want_stat, Tensor(a!) out) -> (Tensor, Tensor, Tensor)", _gat_fwd_, _gat_fwd__fake)
 
 
-def _gat_bwd_(i0, i1, i2, i3, i4, i5, i6, o0, o1, o2, o3, o4, o5, o6, in_pos, out_dst, out_pos, n_heads: int,
+def _gat_bwd_(i0, i1, i2, i3, i4, i5, i6, i7, o0, o1, o2, o3, o4, o5, o6, o7, in_pos, out_dst, out_pos, n_heads: int,
               head_dim: int, hs, eh, stat, ee_table, etype_csr, ee_csc, e_dim: int, slope: float, pre, act_out,
               prelu_w, d_out, d_pre, d_y, want_bias: bool, want_dlogit: bool):
-    s = SimpleNamespace(num_nodes=hs.shape[0], num_edges=int(out_dst.numel()), plan_in=_plan(i0, i1, i2, i3, i4, i5, i6),
-                        plan_out=_plan(o0, o1, o2, o3, o4, o5, o6), in_pos=in_pos, out_dst=out_dst, out_pos=out_pos)
+    s = SimpleNamespace(num_nodes=hs.shape[0], num_edges=int(out_dst.numel()), plan_in=_plan(i0, i1, i2, i3, i4, i5, i6, i7),
+                        plan_out=_plan(o0, o1, o2, o3, o4, o5, o6, o7), in_pos=in_pos, out_dst=out_dst, out_pos=out_pos)
     d_table, d_logit, d_bias, d_prelu = _lib.gat_bwd(s, n_heads, head_dim, hs, eh, stat, ee_table, etype_csr, ee_csc,
                                                      e_dim, slope, pre, act_out, prelu_w, d_out, d_pre, d_y,
                                                      want_bias, want_dlogit)
@@ -170,7 +173,7 @@ def _gat_bwd_(i0, i1, i2, i3, i4, i5, i6, o0, o1, o2, o3, o4, o5, o6, in_pos, ou
             d_bias if d_bias is not None else e, d_prelu if d_prelu is not None else e)
 
 
-def _gat_bwd__fake(i0, i1, i2, i3, i4, i5, i6, o0, o1, o2, o3, o4, o5, o6, in_pos, out_dst, out_pos, n_heads,
+def _gat_bwd__fake(i0, i1, i2, i3, i4, i5, i6, i7, o0, o1, o2, o3, o4, o5, o6, o7, in_pos, out_dst, out_pos, n_heads,
                    head_dim, hs, eh, stat, ee_table, etype_csr, ee_csc, e_dim, slope, pre, act_out, prelu_w, d_out,
                    d_pre, d_y, want_bias, want_dlogit):
     return (hs.new_empty((e_dim, n_heads) if ee_table is not None else (0,)),

@@ -213,10 +213,18 @@ def test_segment_plan_matches_oracle():
     assert np.array_equal(plan.chunk_node.numpy(), cn)
     assert np.array_equal(plan.chunk_beg.numpy(), cb) and np.array_equal(plan.chunk_end.numpy(), ce)
     assert hv.size >= 1 and (ce - cb).max() == CHUNK
-    # walk order: nodes by ascending length class (0 | 1-4 | (4,8] | (8,16] | ...), ties by ascending id
-    deg = np.diff(ptr)
+    # walk order: the node ids cut into 8 ranges of equal work (edges of light segments + 2 per node), inside
+    # a range by ascending length class (0 | 1-4 | (4,8] | (8,16] | ...), ties by ascending id
+    deg = np.diff(ptr).astype(np.int64)
     cls = np.where(deg <= 0, 0, np.where(deg <= 4, 1, np.ceil(np.log2(np.maximum(deg, 1))))).astype(np.int64)
-    assert np.array_equal(plan.order.numpy(), np.argsort(cls, kind="stable").astype(np.int32))
+    cost = np.where(deg <= LIGHT_MAX, deg, 0) + 2
+    xcd = np.minimum((np.cumsum(cost) - cost) * 8 // cost.sum(), 7)
+    assert np.array_equal(plan.order.numpy(), np.argsort(xcd * 64 + cls, kind="stable").astype(np.int32))
+    xs = plan.xcd_start.numpy()
+    assert xs[0] == 0 and xs[8] == n and np.all(np.diff(xs) >= 0)
+    for k in range(8):
+        assert np.all(xcd[xs[k]:xs[k + 1]] == k)
+        assert np.array_equal(np.sort(plan.order.numpy()[xs[k]:xs[k + 1]]), np.arange(xs[k], xs[k + 1]))
     empty = build_segment_plan(torch.zeros(5, dtype=torch.int32))
     assert empty.n_heavy == 0 and empty.n_chunks == 0
 
@@ -416,7 +424,8 @@ def test_custom_ops_are_registered_with_schemas_and_fake_kernels():
         dev = "cuda"
         n, e, h, d = 100, 400, 4, 16
         i32 = dict(dtype=torch.int32, device=dev)
-        plan = [torch.empty(n + 1, **i32)] + [torch.empty(0, **i32) for _ in range(5)] + [torch.empty(n, **i32)]
+        plan = [torch.empty(n + 1, **i32)] + [torch.empty(0, **i32) for _ in range(5)] + \
+            [torch.empty(n, **i32), torch.empty(9, **i32)]
         f = lambda *s: torch.empty(*s, device=dev)   # noqa: E731
         out = f(n, h * d)
         pre, attn, stat = torch.ops.magic.gat_fwd_(*plan, torch.empty(e, **i32), torch.empty(e, **i32), h, d,

@@ -54,7 +54,7 @@ def test_batch_csr_equals_direct_sort(cuda):
     for which in ("plan_in", "plan_out"):
         a, b = getattr(bg.structure, which), getattr(direct, which)
         assert (a.n_heavy, a.n_chunks) == (b.n_heavy, b.n_chunks) and a.n_heavy > 0
-        for name in ("ptr", "heavy_node", "heavy_cptr", "chunk_node", "chunk_beg", "chunk_end", "order"):
+        for name in ("ptr", "heavy_node", "heavy_cptr", "chunk_node", "chunk_beg", "chunk_end", "order", "xcd_start"):
             ta, tb = getattr(a, name), getattr(b, name)
             assert ta.dtype == tb.dtype and torch.equal(ta, tb), (which, name)
 
