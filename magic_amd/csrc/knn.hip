@@ -1,5 +1,16 @@
-// Brute-force k-nearest-neighbour search in float64 on the f64 matrix cores.
+// Brute-force k-nearest-neighbour search: exact float64 results, found in two stages when k is
+// small.
 //
+// Stage 1 (filter) runs the whole Q x N sweep on the float32 matrix cores (twice the float64 rate) and
+// keeps, per query, the k' > k candidates with the smallest APPROXIMATE keys.  Stage 2 (refine)
+// recomputes the float64 key of those k' candidates, orders them by (key, index) and proves the
+// answer: with eps an upper bound of the float32 key error, every row that stage 1 dropped has an
+// exact key >= tau - eps (tau = the k'-th approximate key), so the k best candidates are the k
+// nearest neighbours whenever the k-th exact key is < tau - eps.  Queries that fail the test (more
+// than k' - k rows within 2 eps of the k-th neighbour: heavy near-ties) are compacted on the device and
+// searched again by the float64 kernel below.  The result is the float64 answer in every case.
+//
+// Float64 kernel:
 // key(q, t) = |t|^2 - 2 q.t  orders the train rows of one query exactly like the squared
 // Euclidean distance does (|q|^2 is constant per query and added at the end).  The q.t
 // products come from v_mfma_f64_16x16x4_f64 with float32 inputs widened in registers (a
@@ -12,6 +23,7 @@
 // D[i = (l>>4) + 4*reg][j = l&15].  The K dimension is permuted so that lane group (l>>4)
 // owns 16 contiguous input dims: A and B use the same permutation, the sum is unchanged.
 #include "common.h"
+#include <hipcub/hipcub.hpp>
 #include <math.h>
 
 namespace {
@@ -38,7 +50,14 @@ struct KnnArgs {
     int *part_idx;           // [n_split, Qpad, k]
     int64_t q_pad;
     int lds_lists;
+    // search only the queries qmap[0 .. *qcount) (both device memory), or all when qmap is null
+    const int *qmap;
+    const int *qcount;
 };
+
+// number of queries of this launch and the query row behind position q
+__device__ __forceinline__ int64_t active_queries(const KnnArgs &a) { return a.qmap ? (int64_t)*a.qcount : a.n_query; }
+__device__ __forceinline__ int64_t query_row(const KnnArgs &a, int64_t q) { return a.qmap ? (int64_t)a.qmap[q] : q; }
 
 __global__ __launch_bounds__(256) void k_sqnorm(int64_t n, int d, const float *__restrict__ x, int64_t ld,
                                                 double *__restrict__ out) {
@@ -55,66 +74,60 @@ __global__ __launch_bounds__(256) void k_sqnorm(int64_t n, int d, const float *_
 
 // list access: LDS lists are plain; global lists go through L2 (agent scope) so that every
 // lane of the wave sees the wave's earlier insertions
-template <bool GLOBAL> __device__ __forceinline__ double ld_key(const double *p) {
+template <bool GLOBAL, typename T> __device__ __forceinline__ T ld_rel(const T *p) {
     if (GLOBAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
 }
-template <bool GLOBAL> __device__ __forceinline__ int ld_idx(const int *p) {
-    if (GLOBAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template <bool GLOBAL> __device__ __forceinline__ void st_key(double *p, double v) {
+template <bool GLOBAL, typename T> __device__ __forceinline__ void st_rel(T *p, T v) {
     if (GLOBAL)
         __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
         *p = v;
 }
-template <bool GLOBAL> __device__ __forceinline__ void st_idx(int *p, int v) {
-    if (GLOBAL)
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-        *p = v;
-}
+template <bool GLOBAL> __device__ __forceinline__ double ld_key(const double *p) { return ld_rel<GLOBAL>(p); }
+template <bool GLOBAL> __device__ __forceinline__ int ld_idx(const int *p) { return ld_rel<GLOBAL>(p); }
+template <bool GLOBAL> __device__ __forceinline__ void st_key(double *p, double v) { st_rel<GLOBAL>(p, v); }
+template <bool GLOBAL> __device__ __forceinline__ void st_idx(int *p, int v) { st_rel<GLOBAL>(p, v); }
 
 // Whole-wave sorted insertion of (kv, ti) into the k-entry list of one query (wave-uniform
 // arguments).  Order: ascending (key, index).  Returns the new k-th key.
-template <bool GLOBAL>
-__device__ __forceinline__ double wave_insert(double *L, int *I, int k, double kv, int ti, int lane) {
+template <bool GLOBAL, typename KT>
+__device__ __forceinline__ KT wave_insert(KT *L, int *I, int k, KT kv, int ti, int lane) {
     int pos = 0;
     for (int base = 0; base < k; base += 64) {
         int j = base + lane;
         bool before = false;
         if (j < k) {
-            double v = ld_key<GLOBAL>(L + j);
-            int vi = ld_idx<GLOBAL>(I + j);
+            KT v = ld_rel<GLOBAL>(L + j);
+            int vi = ld_rel<GLOBAL>(I + j);
             before = (v < kv) || (v == kv && vi < ti);
         }
         pos += __popcll(__ballot(before));
     }
-    if (pos >= k) return ld_key<GLOBAL>(L + k - 1);
+    if (pos >= k) return ld_rel<GLOBAL>(L + k - 1);
     for (int base = ((k - 1) / 64) * 64; base >= 0; base -= 64) {
         int j = base + lane;
-        double v = 0.0;
+        KT v = 0;
         int vi = 0;
         bool mv = j >= pos && j + 1 < k;
         if (mv) {
-            v = ld_key<GLOBAL>(L + j);
-            vi = ld_idx<GLOBAL>(I + j);
+            v = ld_rel<GLOBAL>(L + j);
+            vi = ld_rel<GLOBAL>(I + j);
         }
         if (GLOBAL) __builtin_amdgcn_s_waitcnt(0);
         if (mv) {
-            st_key<GLOBAL>(L + j + 1, v);
-            st_idx<GLOBAL>(I + j + 1, vi);
+            st_rel<GLOBAL>(L + j + 1, v);
+            st_rel<GLOBAL>(I + j + 1, vi);
         }
         if (GLOBAL) __builtin_amdgcn_s_waitcnt(0);
     }
     if (lane == 0) {
-        st_key<GLOBAL>(L + pos, kv);
-        st_idx<GLOBAL>(I + pos, ti);
+        st_rel<GLOBAL>(L + pos, kv);
+        st_rel<GLOBAL>(I + pos, ti);
     }
     if (GLOBAL) __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    return ld_key<GLOBAL>(L + k - 1);
+    return ld_rel<GLOBAL>(L + k - 1);
 }
 
 template <bool GLOBAL>
@@ -129,6 +142,8 @@ __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.y;
     const int64_t q_base = (int64_t)blockIdx.x * TQ;
+    const int64_t n_active = active_queries(a);
+    if (q_base >= n_active) return;  // uniform: the whole block leaves
     const int64_t t_lo = (int64_t)split * a.rows_per_split;
     int64_t t_hi = t_lo + a.rows_per_split;
     if (t_hi > a.n_train) t_hi = a.n_train;
@@ -157,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             float v = 0.f;
-            if (q < a.n_query && d0 + j < a.d) v = a.query[q * a.ld_query + d0 + j];
+            if (q < n_active && d0 + j < a.d) v = a.query[query_row(a, q) * a.ld_query + d0 + j];
             bq[qb][j] = (double)v;
         }
     }
@@ -244,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
                             const double kv = __shfl(key[r], srcl, 64);
                             const int ti = __shfl(ti_mine, srcl, 64);
                             if (kv < thr[q_ins]) {
-                                double nt = wave_insert<GLOBAL>(L0 + (int64_t)q_ins * a.k, I0 + (int64_t)q_ins * a.k,
-                                                                a.k, kv, ti, lane);
+                                double nt = wave_insert<GLOBAL, double>(L0 + (int64_t)q_ins * a.k,
+                                                                        I0 + (int64_t)q_ins * a.k, a.k, kv, ti, lane);
                                 if (lane == 0) thr[q_ins] = nt;
                                 __builtin_amdgcn_wave_barrier();
                             }
@@ -266,19 +281,274 @@ __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
     }
 }
 
-// merge the per-split lists of one query, add |q|^2, sqrt, apply the index offset
+// ---- stage 1: approximate keys on the float32 matrix cores ----------------------------------------
+// Same tiling as k_knn_mfma with float operands and v_mfma_f32_16x16x4_f32 (lane l: A[i = l&15][k = l>>4],
+// B[k = l>>4][j = l&15], D[i = 4*(l>>4) + reg][j = l&15]); kf-entry lists (float key, row) in LDS.
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void k_knn_filter(KnnArgs a, int kf, float *fkey, int *fidx) {
+    extern __shared__ __align__(16) char smem[];
+    float *tile = reinterpret_cast<float *>(smem);          // TT*LDT
+    float *tn = tile + TT * LDT;                            // TT
+    float *thr = tn + TT;                                   // TQ
+    float *lkey = thr + TQ;                                 // TQ*kf
+    int *lidx = reinterpret_cast<int *>(lkey + (size_t)TQ * kf);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.y;
+    const int64_t q_base = (int64_t)blockIdx.x * TQ;
+    const int64_t t_lo = (int64_t)split * a.rows_per_split;
+    int64_t t_hi = t_lo + a.rows_per_split;
+    if (t_hi > a.n_train) t_hi = a.n_train;
+    for (int i = tid; i < TQ * kf; i += 256) {
+        lkey[i] = INFINITY;
+        lidx[i] = kIdxNone;
+    }
+    thr[tid] = INFINITY;
+
+    float bq[4][16];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+        int64_t q = q_base + wave * 64 + qb * 16 + (lane & 15);
+        const int d0 = 16 * (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            bq[qb][j] = (q < a.n_query && d0 + j < a.d) ? a.query[q * a.ld_query + d0 + j] : 0.f;
+    }
+    __syncthreads();
+
+    float4 pre[TT / 16];
+    float pre_tn = INFINITY;
+    auto fetch = [&](int64_t t0) {
+#pragma unroll
+        for (int i = 0; i < TT / 16; ++i) {
+            const int r = (tid >> 4) + 16 * i;
+            const int c4 = (tid & 15) * 4;
+            const int64_t row = t0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < t_hi) {
+                const float *p = a.train + row * a.ld_train + c4;
+                if (c4 + 3 < a.d) {
+                    v = *reinterpret_cast<const float4 *>(p);
+                } else {
+                    if (c4 + 0 < a.d) v.x = p[0];
+                    if (c4 + 1 < a.d) v.y = p[1];
+                    if (c4 + 2 < a.d) v.z = p[2];
+                }
+            }
+            pre[i] = v;
+        }
+        if (tid < TT) pre_tn = (t0 + tid < t_hi) ? (float)a.tnorm[t0 + tid] : INFINITY;
+    };
+    if (t_lo < t_hi) fetch(t_lo);
+    for (int64_t t0 = t_lo; t0 < t_hi; t0 += TT) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TT / 16; ++i)
+            *reinterpret_cast<float4 *>(tile + ((tid >> 4) + 16 * i) * LDT + (tid & 15) * 4) = pre[i];
+        if (tid < TT) tn[tid] = pre_tn;
+        __syncthreads();
+        if (t0 + TT < t_hi) fetch(t0 + TT);
+
+#pragma unroll 1
+        for (int tb = 0; tb < TT / 16; ++tb) {
+            float af[16];
+            {
+                const float *p = tile + (tb * 16 + (lane & 15)) * LDT + 16 * (lane >> 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 v = *reinterpret_cast<const float4 *>(p + 4 * j);
+                    af[4 * j + 0] = v.x, af[4 * j + 1] = v.y, af[4 * j + 2] = v.z, af[4 * j + 3] = v.w;
+                }
+            }
+            const float4 tn4 = *reinterpret_cast<const float4 *>(tn + tb * 16 + 4 * (lane >> 4));
+            const float tnr[4] = {tn4.x, tn4.y, tn4.z, tn4.w};
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) {
+                float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bq[qb][ks], acc, 0, 0, 0);
+                const int ql = wave * 64 + qb * 16 + (lane & 15);
+                const float th = thr[ql];
+                float key[4];
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    key[r] = fmaf(-2.f, acc[r], tnr[r]);
+                    any |= key[r] < th;
+                }
+                if (__any(any)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        unsigned long long mask = __ballot(key[r] < th);
+                        const int ti_mine = (int)(t0 + tb * 16 + 4 * (lane >> 4) + r);
+                        while (mask) {
+                            const int srcl = __ffsll((long long)mask) - 1;
+                            mask &= mask - 1;
+                            const int q_ins = __shfl(ql, srcl, 64);
+                            const float kv = __shfl(key[r], srcl, 64);
+                            const int ti = __shfl(ti_mine, srcl, 64);
+                            if (kv < thr[q_ins]) {
+                                float nt = wave_insert<false, float>(lkey + (size_t)q_ins * kf, lidx + (size_t)q_ins * kf, kf,
+                                                                     kv, ti, lane);
+                                if (lane == 0) thr[q_ins] = nt;
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float *gk = fkey + ((int64_t)split * a.q_pad + q_base) * kf;
+    int *gi = fidx + ((int64_t)split * a.q_pad + q_base) * kf;
+    for (int i = tid; i < TQ * kf; i += 256) {
+        gk[i] = lkey[i];
+        gi[i] = lidx[i];
+    }
+}
+
+// largest squared train norm (bit pattern of a non-negative double orders like the value)
+__global__ __launch_bounds__(256) void k_tmax(int64_t n, const double *tnorm, unsigned long long *out) {
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmax(m, tnorm[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
+// exact float64 key of (query row, train row): the arithmetic every reported distance comes from
+__device__ __forceinline__ double exact_key(const KnnArgs &a, const float *qr, int ti) {
+    const float *tr = a.train + (int64_t)ti * a.ld_train;
+    double dot = 0.0;
+    for (int j = 0; j < a.d; ++j) dot = fma((double)qr[j], (double)tr[j], dot);
+    return fma(-2.0, dot, a.tnorm[ti]);
+}
+
+constexpr int KF_MAX = 32;
+
+// sort n (key, index) pairs ascending by (key, index); n <= KF_MAX
+__device__ __forceinline__ void sort_pairs(double *K, int *I, int n) {
+    for (int i = 1; i < n; ++i) {
+        const double kv = K[i];
+        const int iv = I[i];
+        int j = i - 1;
+        while (j >= 0 && (K[j] > kv || (K[j] == kv && I[j] > iv))) {
+            K[j + 1] = K[j], I[j + 1] = I[j];
+            --j;
+        }
+        K[j + 1] = kv, I[j + 1] = iv;
+    }
+}
+
+// ---- stage 2: exact keys of the kf candidates of every query, proof, output -------------------------
+// One thread per query.  flag[q] = 1 when the proof fails (the query goes to the float64 search).
+__global__ __launch_bounds__(128) void k_knn_refine(KnnArgs a, int kf, const float *fkey, const int *fidx,
+                                                    const unsigned long long *tmax_bits, int64_t index_offset,
+                                                    double *dist, int64_t *idx, int *flag) {
+    const int64_t q = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (q >= a.n_query) return;
+    const float *qr = a.query + q * a.ld_query;
+    double qn = 0.0;
+    for (int j = 0; j < a.d; ++j) qn = fma((double)qr[j], (double)qr[j], qn);
+    // the kf smallest approximate keys over the per-split lists, ascending (key, row)
+    double K[KF_MAX];
+    int I[KF_MAX];
+    int cur[64];
+    for (int s = 0; s < a.n_split; ++s) cur[s] = 0;
+    int n = 0;
+    float tau = INFINITY;  // approximate key of the kf-th candidate: no dropped row lies below it
+    for (int o = 0; o < kf; ++o) {
+        float best = INFINITY;
+        int bi = kIdxNone, bs = -1;
+        for (int s = 0; s < a.n_split; ++s) {
+            if (cur[s] >= kf) continue;
+            const int64_t off = ((int64_t)s * a.q_pad + q) * kf + cur[s];
+            const float v = fkey[off];
+            const int vi = fidx[off];
+            if (vi != kIdxNone && (bs < 0 || v < best || (v == best && vi < bi))) best = v, bi = vi, bs = s;
+        }
+        if (bs < 0) break;
+        cur[bs]++;
+        I[n++] = bi;
+        if (o == kf - 1) tau = best;
+    }
+    for (int c = 0; c < n; ++c) K[c] = exact_key(a, qr, I[c]);
+    sort_pairs(K, I, n);
+    // error bound of a float32 key: d + 3 roundings of the dot product, the rounded norm, the final fma
+    const double tmax = sqrt(__longlong_as_double((long long)*tmax_bits)), qs = sqrt(qn);
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    const double eps = 2.0 * (2.0 * (a.d + 4) * u * qs * tmax + 2.0 * u * (tmax * tmax + 2.0 * qs * tmax));
+    const bool complete = n < kf;  // fewer candidates than list entries: every train row is a candidate
+    const bool proven = complete || (a.k <= n && K[a.k - 1] < (double)tau - eps);
+    flag[q] = proven ? 0 : 1;
+    for (int o = 0; o < a.k; ++o) {
+        const bool ok = o < n;
+        const double d2 = ok ? K[o] + qn : 0.0;
+        dist[q * a.k + o] = ok ? sqrt(d2 > 0.0 ? d2 : 0.0) : (double)INFINITY;
+        idx[q * a.k + o] = ok ? (int64_t)I[o] + index_offset : (int64_t)-1;
+    }
+}
+
+// float64 search results of the compacted queries: merge the per-split lists, recompute the keys of the
+// k rows with the arithmetic of exact_key (so that both stages report bit-identical distances for the
+// same pair), order by (key, row) and write to the query's own row
+__global__ __launch_bounds__(128) void k_knn_finalize_compact(KnnArgs a, int64_t index_offset, double *dist, int64_t *idx) {
+    const int64_t p = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (p >= (int64_t)*a.qcount) return;
+    const int64_t q = a.qmap[p];
+    const float *qr = a.query + q * a.ld_query;
+    double qn = 0.0;
+    for (int j = 0; j < a.d; ++j) qn = fma((double)qr[j], (double)qr[j], qn);
+    double K[KF_MAX];
+    int I[KF_MAX];
+    int cur[64];
+    for (int s = 0; s < a.n_split; ++s) cur[s] = 0;
+    int n = 0;
+    for (int o = 0; o < a.k; ++o) {
+        double best = INFINITY;
+        int bi = kIdxNone, bs = -1;
+        for (int s = 0; s < a.n_split; ++s) {
+            if (cur[s] >= a.k) continue;
+            const int64_t off = ((int64_t)s * a.q_pad + p) * a.k + cur[s];
+            const double v = a.part_key[off];
+            const int vi = a.part_idx[off];
+            if (vi != kIdxNone && (bs < 0 || v < best || (v == best && vi < bi))) best = v, bi = vi, bs = s;
+        }
+        if (bs < 0) break;
+        cur[bs]++;
+        I[n++] = bi;
+    }
+    for (int c = 0; c < n; ++c) K[c] = exact_key(a, qr, I[c]);
+    sort_pairs(K, I, n);
+    for (int o = 0; o < a.k; ++o) {
+        const bool ok = o < n;
+        const double d2 = ok ? K[o] + qn : 0.0;
+        dist[q * a.k + o] = ok ? sqrt(d2 > 0.0 ? d2 : 0.0) : (double)INFINITY;
+        idx[q * a.k + o] = ok ? (int64_t)I[o] + index_offset : (int64_t)-1;
+    }
+}
+
+// merge the per-split lists of one query; recompute the keys of the k rows with the arithmetic of
+// exact_key (every search path reports the same bits for the same pair, so per-shard results merge
+// into the single-search result whatever path each shard took), order by (key, row), add |q|^2,
+// sqrt, apply the index offset
 __global__ __launch_bounds__(256) void k_knn_finalize(KnnArgs a, int64_t index_offset, double *dist, int64_t *idx) {
     int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= a.n_query) return;
+    const float *qr = a.query + q * a.ld_query;
     double qn = 0.0;
     for (int j = 0; j < a.d; ++j) {
-        double v = (double)a.query[q * a.ld_query + j];
+        double v = (double)qr[j];
         qn = fma(v, v, qn);
     }
-    // heads of the n_split sorted lists live in registers only for small n_split; use a
-    // simple cursor array in local memory otherwise (n_split <= 64)
+    double *K = dist + q * a.k;
+    int64_t *I = idx + q * a.k;
     int cur[64];
     for (int s = 0; s < a.n_split; ++s) cur[s] = 0;
+    int n = 0;
     for (int o = 0; o < a.k; ++o) {
         double best = INFINITY;
         int bi = kIdxNone, bs = -1;
@@ -287,16 +557,33 @@ __global__ __launch_bounds__(256) void k_knn_finalize(KnnArgs a, int64_t index_o
             int64_t off = ((int64_t)s * a.q_pad + q) * a.k + cur[s];
             double v = a.part_key[off];
             int vi = a.part_idx[off];
-            if (v < best || (v == best && vi < bi)) {
+            if (vi != kIdxNone && (bs < 0 || v < best || (v == best && vi < bi))) {
                 best = v;
                 bi = vi;
                 bs = s;
             }
         }
-        if (bs >= 0) cur[bs]++;
-        double d2 = best + qn;
-        dist[q * a.k + o] = bs >= 0 && bi != kIdxNone ? sqrt(d2 > 0.0 ? d2 : 0.0) : (double)INFINITY;
-        idx[q * a.k + o] = bs >= 0 && bi != kIdxNone ? (int64_t)bi + index_offset : (int64_t)-1;
+        if (bs < 0) break;
+        cur[bs]++;
+        I[n] = bi;
+        K[n] = exact_key(a, qr, bi);
+        ++n;
+    }
+    for (int i = 1; i < n; ++i) {  // nearly sorted already: the two arithmetics differ in the last bits only
+        const double kv = K[i];
+        const int64_t iv = I[i];
+        int j = i - 1;
+        while (j >= 0 && (K[j] > kv || (K[j] == kv && I[j] > iv))) {
+            K[j + 1] = K[j], I[j + 1] = I[j];
+            --j;
+        }
+        K[j + 1] = kv, I[j + 1] = iv;
+    }
+    for (int o = 0; o < a.k; ++o) {
+        const bool ok = o < n;
+        const double d2 = ok ? K[o] + qn : 0.0;
+        K[o] = ok ? sqrt(d2 > 0.0 ? d2 : 0.0) : (double)INFINITY;
+        I[o] = ok ? I[o] + index_offset : (int64_t)-1;
     }
 }
 
@@ -423,8 +710,68 @@ void plan_split(int64_t n_train, int64_t n_query, int *n_split, int64_t *rows_pe
     *rows_per_split = tps * TT;
 }
 
+// ---- two-stage search: sizes ---------------------------------------------------------------------
+// candidates kept per query by the filter: k plus a margin for near-ties
+int filter_kf(int k) { return k + (k / 2 > 6 ? k / 2 : 6); }
+size_t filter_lds_bytes(int kf) { return (size_t)TT * LDT * 4 + (size_t)TT * 4 + (size_t)TQ * 4 + (size_t)TQ * kf * 8; }
+// the filter pays off for small k (lists in LDS, two blocks per CU) and problems that fill the chip
+bool filter_eligible(int64_t n_train, int64_t n_query, int d, int k) {
+    const int kf = filter_kf(k);
+    return d >= 1 && d <= DP && kf <= KF_MAX && kf <= n_train && filter_lds_bytes(kf) <= 64 * 1024 && n_train >= 4096 &&
+           n_query >= 64;
+}
+// split of the float64 search over the queries the proof rejects
+void plan_fallback(int64_t n_train, int64_t n_query, int *n_split, int64_t *rows_per_split);
+
+struct FilterWs {
+    float *fkey;
+    int *fidx;
+    unsigned long long *tmax;
+    int *flag, *qmap, *qcount;
+    void *cub;
+    size_t cub_bytes;
+    double *part_key;
+    int *part_idx;
+    int ns_f, ns_x;
+    int64_t rps_f, rps_x, q_pad;
+};
+
 size_t lds_bytes(int k, bool lds_lists) {
     return (size_t)TT * LDT * 4 + (size_t)TT * 8 + (size_t)TQ * 8 + (lds_lists ? (size_t)TQ * k * 12 : 0);
+}
+
+void plan_fallback(int64_t n_train, int64_t n_query, int *n_split, int64_t *rows_per_split) {
+    // Few queries are expected here, so the train rows are cut finely (up to 16 ways: a block's sweep, the
+    // least this stage can take, shrinks with the cut); the lists are sized for every query, which bounds
+    // the cut (16 x Q x k x 12 bytes).
+    const int64_t tiles = (n_train + TT - 1) / TT;
+    int64_t s = tiles / 8 > 0 ? tiles / 8 : 1;  // at least 8 tiles per split
+    if (s > 16) s = 16;
+    const int64_t tps = (tiles + s - 1) / s;
+    *n_split = (int)((tiles + tps - 1) / tps);
+    *rows_per_split = tps * TT;
+    (void)n_query;
+}
+
+// carve the two-stage workspace (after the train norms) out of `ar`; false when it does not fit
+bool filter_workspace(magic::Arena &ar, int64_t n_train, int64_t n_query, int k, FilterWs *w) {
+    const int kf = filter_kf(k);
+    plan_split(n_train, n_query, &w->ns_f, &w->rps_f);
+    plan_fallback(n_train, n_query, &w->ns_x, &w->rps_x);
+    w->q_pad = (n_query + TQ - 1) / TQ * TQ;
+    w->fkey = ar.take<float>((size_t)w->ns_f * w->q_pad * kf);
+    w->fidx = ar.take<int>((size_t)w->ns_f * w->q_pad * kf);
+    w->tmax = ar.take<unsigned long long>(1);
+    w->flag = ar.take<int>((size_t)w->q_pad);
+    w->qmap = ar.take<int>((size_t)w->q_pad);
+    w->qcount = ar.take<int>(1);
+    w->cub_bytes = 0;
+    hipcub::DeviceSelect::Flagged(nullptr, w->cub_bytes, hipcub::CountingInputIterator<int>(0), (const int *)nullptr,
+                                  (int *)nullptr, (int *)nullptr, (int)n_query);
+    w->cub = ar.take<char>(w->cub_bytes + 256);
+    w->part_key = ar.take<double>((size_t)w->ns_x * w->q_pad * k);
+    w->part_idx = ar.take<int>((size_t)w->ns_x * w->q_pad * k);
+    return ar.ok();
 }
 
 }  // namespace
@@ -434,6 +781,13 @@ extern "C" {
 size_t magic_knn_workspace_bytes(int64_t n_train, int64_t n_query, int32_t d, int32_t k) {
     if (n_train <= 0 || n_query <= 0 || d <= 0 || k <= 0) return 256;
     size_t b = magic::align_up((size_t)n_train * 8);
+    if (filter_eligible(n_train, n_query, d, k)) {
+        // measure the carve-up on a huge pretend buffer
+        magic::Arena ar(reinterpret_cast<void *>(256), (size_t)1 << 60);
+        FilterWs w;
+        filter_workspace(ar, n_train, n_query, k, &w);
+        return b + ar.off + 256;
+    }
     if (mfma_path(d)) {
         int ns;
         int64_t rps;
@@ -469,7 +823,58 @@ int magic_knn_topk(int64_t n_train, int64_t n_query, int32_t d, int32_t k, const
     a.tnorm = tnorm;
     MAGIC_LAUNCH("knn_sqnorm", k_sqnorm, magic::stride_grid(n_train, 256), 256, 0, stream, n_train, d, train, ld_train,
                  tnorm);
-    if (mfma_path(d)) {
+    a.qmap = nullptr;
+    a.qcount = nullptr;
+    if (filter_eligible(n_train, n_query, d, k)) {
+        if ((ld_train % 4) != 0 || ((uintptr_t)train % 16) != 0) return MAGIC_ERR_INVALID_ARG;  // float4 row loads
+        const int kf = filter_kf(k);
+        FilterWs w;
+        if (!filter_workspace(ar, n_train, n_query, k, &w)) return MAGIC_ERR_WORKSPACE;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void *)k_knn_filter, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) !=
+                hipSuccess)
+                return MAGIC_ERR_RUNTIME;
+            attr_set = true;
+        }
+        if (hipMemsetAsync(w.tmax, 0, sizeof(unsigned long long), stream) != hipSuccess) return MAGIC_ERR_RUNTIME;
+        MAGIC_LAUNCH("knn_tmax", k_tmax, magic::stride_grid(n_train, 256 * 16, 1024), 256, 0, stream, n_train, tnorm, w.tmax);
+        // stage 1
+        a.q_pad = w.q_pad;
+        a.n_split = w.ns_f;
+        a.rows_per_split = w.rps_f;
+        a.part_key = nullptr;
+        a.part_idx = nullptr;
+        a.lds_lists = 1;
+        dim3 fgrid((unsigned)(a.q_pad / TQ), (unsigned)a.n_split);
+        MAGIC_LAUNCH("knn_filter_f32_mfma", k_knn_filter, fgrid, 256, filter_lds_bytes(kf), stream, a, kf, w.fkey, w.fidx);
+        // stage 2: exact keys of the candidates, proof, output; rejected queries flagged
+        MAGIC_LAUNCH("knn_refine", k_knn_refine, (unsigned)((n_query + 127) / 128), 128, 0, stream, a, kf, w.fkey, w.fidx,
+                     w.tmax, index_offset, dist, idx, w.flag);
+        // rejected queries -> compact list, searched in float64
+        {
+            magic::ProfScope ps("knn_compact", stream);
+            size_t cb = w.cub_bytes;
+            if (hipcub::DeviceSelect::Flagged(w.cub, cb, hipcub::CountingInputIterator<int>(0), w.flag, w.qmap, w.qcount,
+                                              (int)n_query, stream) != hipSuccess)
+                return MAGIC_ERR_RUNTIME;
+        }
+        a.qmap = w.qmap;
+        a.qcount = w.qcount;
+        a.n_split = w.ns_x;
+        a.rows_per_split = w.rps_x;
+        a.part_key = w.part_key;
+        a.part_idx = w.part_idx;
+        a.lds_lists = lds_bytes(k, true) <= 64 * 1024;
+        dim3 xgrid((unsigned)(a.q_pad / TQ), (unsigned)a.n_split);
+        size_t sh = lds_bytes(k, a.lds_lists);
+        if (a.lds_lists)
+            MAGIC_LAUNCH("knn_topk_f64_mfma", (k_knn_mfma<false>), xgrid, 256, sh, stream, a);
+        else
+            MAGIC_LAUNCH("knn_topk_f64_mfma", (k_knn_mfma<true>), xgrid, 256, sh, stream, a);
+        MAGIC_LAUNCH("knn_finalize", k_knn_finalize_compact, (unsigned)((n_query + 127) / 128), 128, 0, stream, a,
+                     index_offset, dist, idx);
+    } else if (mfma_path(d)) {
         if ((ld_train % 4) != 0 || ((uintptr_t)train % 16) != 0) return MAGIC_ERR_INVALID_ARG;  // float4 row loads
         plan_split(n_train, n_query, &a.n_split, &a.rows_per_split);
         a.q_pad = (n_query + TQ - 1) / TQ * TQ;

@@ -93,6 +93,51 @@ def test_knn_ties_ordered_by_index_and_merge(cuda):
     assert torch.equal(mi, idx) and torch.equal(md, dist)
 
 
+@pytest.mark.parametrize("kind", ["clusters", "duplicates", "near_ties"])
+def test_knn_two_stage_search_is_exact(cuda, kind):
+    """Problems large enough for the float32 filter + float64 refine path: the answer must be the exact
+    float64 one whether the proof passes (well separated neighbours) or the query falls back to the
+    float64 sweep (many rows at the same or nearly the same distance as the k-th neighbour)."""
+    from magic_amd import _lib
+    rng = np.random.default_rng(11)
+    d, k, nt, nq = 64, 10, 12000, 600
+    centers = rng.standard_normal((20, d)).astype(np.float32)
+    if kind == "clusters":
+        train = centers[rng.integers(0, 20, nt)] + 0.05 * rng.standard_normal((nt, d)).astype(np.float32)
+        query = centers[rng.integers(0, 20, nq)] + 0.05 * rng.standard_normal((nq, d)).astype(np.float32)
+    elif kind == "duplicates":
+        base = centers[rng.integers(0, 20, 300)] + 0.05 * rng.standard_normal((300, d)).astype(np.float32)
+        train = base[rng.integers(0, 300, nt)]                       # every row about 40 times
+        query = base[rng.integers(0, 300, nq)] + (rng.random((nq, 1)) < 0.5) * 0.01
+    else:
+        base = centers[rng.integers(0, 20, 300)] + 0.05 * rng.standard_normal((300, d)).astype(np.float32)
+        train = base[rng.integers(0, 300, nt)] + 1e-6 * rng.standard_normal((nt, d)).astype(np.float32)
+        query = base[rng.integers(0, 300, nq)] + 0.01
+    train, query = train.astype(np.float32), query.astype(np.float32)
+    t, q = torch.from_numpy(train).to(cuda), torch.from_numpy(query).to(cuda)
+    dist, idx = _lib.knn_topk(t, q, k)
+    # blocks small enough for the oracle's direct (q - t)^2 form: identical rows get identical distances there
+    wd, wi = knn_oracle.exact_topk(train, query, k, block=200)
+    got_i, got_d = idx.cpu().numpy(), dist.cpu().numpy()
+    assert np.abs(got_d - wd).max() < 1e-6
+    if kind == "near_ties":
+        # keys that differ by less than float64 rounding of the two distance formulas may swap: compare the
+        # distances of the rows each side picked instead of the ids
+        mine = np.sqrt(((query[:, None, :].astype(np.float64) - train[got_i].astype(np.float64)) ** 2).sum(-1))
+        assert np.abs(mine - wd).max() < 1e-6
+    else:
+        assert np.array_equal(got_i, wi)
+    # the same search sharded over three train ranges and merged gives the single-search result bit for bit
+    parts_d, parts_i = [], []
+    for lo in (0, 5000, 10000):
+        hi = min(lo + 5000, nt)
+        d_, i_ = _lib.knn_topk(t[lo:hi], q, k, lo)
+        parts_d.append(d_)
+        parts_i.append(i_)
+    md, mi = _lib.knn_merge(torch.stack(parts_d), torch.stack(parts_i))
+    assert torch.equal(mi, idx) and torch.equal(md, dist)
+
+
 @pytest.mark.parametrize("n_dim,alpha,single", [(5, 3, False), (11, 3, True), (8, 2, False), (8, 1.5, True)])
 def test_sce_kernel(cuda, n_dim, alpha, single):
     from magic_amd.model.loss_func import sce_loss_masked

@@ -55,7 +55,7 @@ def main():
     lph_of = {}     # head count -> lanes per head of this workload's layers (from the two-argument templates)
     for k in traffic:
         args = k.split("<", 1)[1].rstrip(">").replace(" ", "").split(",") if "<" in k else []
-        if k.startswith("k_bwd_src_light<") and len(args) == 2:
+        if k.startswith("k_fwd_light<") and len(args) >= 2:
             lph_of[args[0]] = args[1]
     for k, v in traffic.items():
         base = k.split("<")[0]
@@ -63,6 +63,7 @@ def main():
             args = k.split("<", 1)[1].rstrip(">").replace(" ", "").split(",")
             if len(args) == 1 or base == "k_edge_logits":      # templated on the head count only
                 args = [args[0], lph_of.get(args[0], "?")]
+            args = args[:2]                                     # (heads, lanes per head); drop further flags
             out[BENCH_NAME[base] + "<" + ",".join(args) + ">"] = int(v)
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
     path = os.path.join(root, "traffic.json")
