@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec
 F64_MFMA_PEAK_TF = 78.6    # MI355X fp64 matrix spec
 F32_MFMA_PEAK_TF = 157.3   # MI355X fp32 matrix spec
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X dense bf16 matrix peak (without structured sparsity)
 FWD_KIND = "fwd_unfused"    # byte model of the forward sweep (sweep_bytes)
 
 
@@ -575,20 +576,23 @@ def knn_leg(args, world, rank, dev):
            "config": {"workload": f"E3-Trace-shaped outlier scoring: train {nt} x {d} f32 sharded over {world} rank(s), "
                                   f"all {nq} test rows per step, k={k}; standardise + mean_distance search of "
                                   f"{n_sample} train rows + test search + row mean + score, all on the device"}}
-    # dominant kernel: the float32 matrix-core filter of the two-stage search (every query-train pair goes
-    # through it once; the float64 stages only touch the k' candidates and the queries the proof rejects)
-    name, peak = ("knn_filter_f32_mfma", F32_MFMA_PEAK_TF) if "knn_filter_f32_mfma" in prof else \
-        ("knn_topk_f64_mfma", F64_MFMA_PEAK_TF)
+    # dominant kernel: the matrix-core filter of the two-stage search (every query-train pair goes through it
+    # once; the float64 stages only touch the k' candidates and the queries the proof rejects).  It forms one
+    # float32-grade product from six bf16 matrix products, so its roofline is the dense bf16 peak / 6.
+    if "knn_filter_bf16x6_mfma" in prof:
+        name, peak, arith = "knn_filter_bf16x6_mfma", BF16_MFMA_PEAK_TF / 6.0, \
+            "split-bf16 matrix-core filter (6 bf16 products per float32-grade product), f64 refine + proof, " \
+            "f64 sweep for rejected queries"
+    else:
+        name, peak, arith = "knn_topk_f64_mfma", F64_MFMA_PEAK_TF, "f64 matrix cores"
     if name in prof:
         cnt, tot_ms = prof[name]
         flops = 2.0 * (nq + n_sample) * (hi - lo) * d * args.knn_steps      # both searches of every step
         ach = flops / (tot_ms * 1e-3) / 1e12
-        res["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+        res["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                            "launches_per_step": cnt // args.knn_steps,
-                           "kernel_ms_per_step": round(tot_ms / args.knn_steps, 3),
-                           "arithmetic": "f32 matrix-core filter, f64 refine + proof, f64 sweep for rejected queries"
-                           if name.startswith("knn_filter") else "f64 matrix cores"}
+                           "kernel_ms_per_step": round(tot_ms / args.knn_steps, 3), "arithmetic": arith}
         res["kernels"] = {kname: {"launches": c, "total_ms_per_step": round(t / args.knn_steps, 3)}
                           for kname, (c, t) in sorted(prof.items(), key=lambda kv: -kv[1][1])}
     return res

@@ -1,10 +1,11 @@
 // Brute-force k-nearest-neighbour search: exact float64 results, found in two stages when k is
 // small.
 //
-// Stage 1 (filter) runs the whole Q x N sweep on the float32 matrix cores (twice the float64 rate) and
-// keeps, per query, the k' > k candidates with the smallest APPROXIMATE keys.  Stage 2 (refine)
+// Stage 1 (filter) runs the whole Q x N sweep on the bf16 matrix cores with split float32 operands
+// (float32-grade products at more than five times the float64 matrix rate) and keeps, per query, the
+// k' > k candidates with the smallest APPROXIMATE keys.  Stage 2 (refine)
 // recomputes the float64 key of those k' candidates, orders them by (key, index) and proves the
-// answer: with eps an upper bound of the float32 key error, every row that stage 1 dropped has an
+// answer: with eps an upper bound of the stage-1 key error, every row that stage 1 dropped has an
 // exact key >= tau - eps (tau = the k'-th approximate key), so the k best candidates are the k
 // nearest neighbours whenever the k-th exact key is < tau - eps.  Queries that fail the test (more
 // than k' - k rows within 2 eps of the k-th neighbour: heavy near-ties) are compacted on the device and
@@ -23,6 +24,7 @@
 // D[i = (l>>4) + 4*reg][j = l&15].  The K dimension is permuted so that lane group (l>>4)
 // owns 16 contiguous input dims: A and B use the same permutation, the sum is unchanged.
 #include "common.h"
+#include "bf16_split.h"
 #include <hipcub/hipcub.hpp>
 #include <math.h>
 
@@ -281,20 +283,33 @@ __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
     }
 }
 
-// ---- stage 1: approximate keys on the float32 matrix cores ----------------------------------------
-// Same tiling as k_knn_mfma with float operands and v_mfma_f32_16x16x4_f32 (lane l: A[i = l&15][k = l>>4],
-// B[k = l>>4][j = l&15], D[i = 4*(l>>4) + reg][j = l&15]); kf-entry lists (float key, row) in LDS.
-typedef float float4_t __attribute__((ext_vector_type(4)));
+// ---- stage 1: approximate keys on the bf16 matrix cores, float32-grade from split operands ---------
+// Every float32 operand is the sum of three bf16 pieces and the six leading cross products are
+// accumulated in float32 (bf16_split.h): 6 x 32 cycles per 32x32x16 step against 4 x 4 x 32 cycles of
+// v_mfma_f32_16x16x4_f32 for the same products, 2.7 times the float32 matrix rate.  What is dropped
+// (2^-23 |q||t| per product) goes into the error bound of the proof in stage 2.
+// Block: 256 queries, wave w owns query tiles 2w and 2w+1 (32 queries each) with their split fragments
+// in registers for the whole sweep; the 64-row train tile is split while it is staged into LDS (three
+// planes of [64][72] bf16: the 16-byte fragment reads of 16 consecutive lanes cover all 64 banks once).
+// v_mfma_f32_32x32x16_bf16 (lane l): A[i = l&31][k = 8*(l>>5) ..+7], B[k = 8*(l>>5) ..+7][j = l&31],
+// D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31], r = 0..15.
+constexpr int BLD = DP + 8;             // bf16 per staged train row
+constexpr int BPLANE = TT * BLD;        // bf16 per plane
+typedef float float16_t __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256, 2) void k_knn_filter(KnnArgs a, int kf, float *fkey, int *fidx) {
+__global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, float *fkey, int *fidx) {
+    using magic::bf16x2_t;
+    using magic::bf16x8_t;
+    using magic::f32x2_t;
     extern __shared__ __align__(16) char smem[];
-    float *tile = reinterpret_cast<float *>(smem);          // TT*LDT
-    float *tn = tile + TT * LDT;                            // TT
-    float *thr = tn + TT;                                   // TQ
-    float *lkey = thr + TQ;                                 // TQ*kf
+    __bf16 *tile = reinterpret_cast<__bf16 *>(smem);                 // 3 * BPLANE
+    float *tn = reinterpret_cast<float *>(smem + 3 * BPLANE * 2);    // TT
+    float *thr = tn + TT;                                            // TQ
+    float *lkey = thr + TQ;                                          // TQ*kf
     int *lidx = reinterpret_cast<int *>(lkey + (size_t)TQ * kf);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, hf = lane >> 5;
     const int split = blockIdx.y;
     const int64_t q_base = (int64_t)blockIdx.x * TQ;
     const int64_t t_lo = (int64_t)split * a.rows_per_split;
@@ -306,14 +321,22 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter(KnnArgs a, int kf, float 
     }
     thr[tid] = INFINITY;
 
-    float bq[4][16];
+    // query fragments: tile ct, K step s -> dims [16 s + 8 hf, +8) of query (2 wave + ct) * 32 + lr
+    bf16x8_t bq[2][4][3];
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
-        int64_t q = q_base + wave * 64 + qb * 16 + (lane & 15);
-        const int d0 = 16 * (lane >> 4);
+    for (int ct = 0; ct < 2; ++ct) {
+        const int64_t q = q_base + (2 * wave + ct) * 32 + lr;
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            bq[qb][j] = (q < a.n_query && d0 + j < a.d) ? a.query[q * a.ld_query + d0 + j] : 0.f;
+        for (int s = 0; s < 4; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int dj = 16 * s + 8 * hf + j;
+                v[j] = (q < a.n_query && dj < a.d) ? a.query[q * a.ld_query + dj] : 0.f;
+            }
+            magic::split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), bq[ct][s][0],
+                          bq[ct][s][1], bq[ct][s][2]);
+        }
     }
     __syncthreads();
 
@@ -340,49 +363,63 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter(KnnArgs a, int kf, float 
         }
         if (tid < TT) pre_tn = (t0 + tid < t_hi) ? (float)a.tnorm[t0 + tid] : INFINITY;
     };
+    union Pack4 {
+        bf16x2_t h[2];
+        uint2 u;
+    };
     if (t_lo < t_hi) fetch(t_lo);
     for (int64_t t0 = t_lo; t0 < t_hi; t0 += TT) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < TT / 16; ++i)
-            *reinterpret_cast<float4 *>(tile + ((tid >> 4) + 16 * i) * LDT + (tid & 15) * 4) = pre[i];
+        for (int i = 0; i < TT / 16; ++i) {  // four consecutive k of one row -> 8 bytes in each plane
+            Pack4 p1, p2, p3;
+            magic::split2(f32x2_t{pre[i].x, pre[i].y}, p1.h[0], p2.h[0], p3.h[0]);
+            magic::split2(f32x2_t{pre[i].z, pre[i].w}, p1.h[1], p2.h[1], p3.h[1]);
+            __bf16 *dst = tile + ((tid >> 4) + 16 * i) * BLD + (tid & 15) * 4;
+            *reinterpret_cast<uint2 *>(dst) = p1.u;
+            *reinterpret_cast<uint2 *>(dst + BPLANE) = p2.u;
+            *reinterpret_cast<uint2 *>(dst + 2 * BPLANE) = p3.u;
+        }
         if (tid < TT) tn[tid] = pre_tn;
         __syncthreads();
         if (t0 + TT < t_hi) fetch(t0 + TT);
 
 #pragma unroll 1
-        for (int tb = 0; tb < TT / 16; ++tb) {
-            float af[16];
-            {
-                const float *p = tile + (tb * 16 + (lane & 15)) * LDT + 16 * (lane >> 4);
+        for (int rt = 0; rt < TT / 32; ++rt) {
+            bf16x8_t af[4][3];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float4 v = *reinterpret_cast<const float4 *>(p + 4 * j);
-                    af[4 * j + 0] = v.x, af[4 * j + 1] = v.y, af[4 * j + 2] = v.z, af[4 * j + 3] = v.w;
-                }
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    af[s][pl] = *reinterpret_cast<const bf16x8_t *>(tile + pl * BPLANE + (rt * 32 + lr) * BLD + 16 * s + 8 * hf);
+            float tnr[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(tn + rt * 32 + 8 * g + 4 * hf);
+                tnr[4 * g + 0] = t4.x, tnr[4 * g + 1] = t4.y, tnr[4 * g + 2] = t4.z, tnr[4 * g + 3] = t4.w;
             }
-            const float4 tn4 = *reinterpret_cast<const float4 *>(tn + tb * 16 + 4 * (lane >> 4));
-            const float tnr[4] = {tn4.x, tn4.y, tn4.z, tn4.w};
 #pragma unroll
-            for (int qb = 0; qb < 4; ++qb) {
-                float4_t acc = {0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < 2; ++ct) {
+                float16_t acc;
 #pragma unroll
-                for (int ks = 0; ks < 16; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bq[qb][ks], acc, 0, 0, 0);
-                const int ql = wave * 64 + qb * 16 + (lane & 15);
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    magic::mfma_split6(acc, af[s][0], af[s][1], af[s][2], bq[ct][s][0], bq[ct][s][1], bq[ct][s][2]);
+                const int ql = (2 * wave + ct) * 32 + lr;
                 const float th = thr[ql];
-                float key[4];
+                float key[16];
                 bool any = false;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 16; ++r) {
                     key[r] = fmaf(-2.f, acc[r], tnr[r]);
                     any |= key[r] < th;
                 }
                 if (__any(any)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < 16; ++r) {
                         unsigned long long mask = __ballot(key[r] < th);
-                        const int ti_mine = (int)(t0 + tb * 16 + 4 * (lane >> 4) + r);
+                        const int ti_mine = (int)(t0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf);
                         while (mask) {
                             const int srcl = __ffsll((long long)mask) - 1;
                             mask &= mask - 1;
@@ -446,8 +483,8 @@ __device__ __forceinline__ void sort_pairs(double *K, int *I, int n) {
 // ---- stage 2: exact keys of the kf candidates of every query, proof, output -------------------------
 // One thread per query.  flag[q] = 1 when the proof fails (the query goes to the float64 search).
 __global__ __launch_bounds__(128) void k_knn_refine(KnnArgs a, int kf, const float *fkey, const int *fidx,
-                                                    const unsigned long long *tmax_bits, int64_t index_offset,
-                                                    double *dist, int64_t *idx, int *flag) {
+                                                    const unsigned long long *tmax_bits, double gamma,
+                                                    int64_t index_offset, double *dist, int64_t *idx, int *flag) {
     const int64_t q = (int64_t)blockIdx.x * 128 + threadIdx.x;
     if (q >= a.n_query) return;
     const float *qr = a.query + q * a.ld_query;
@@ -477,10 +514,12 @@ __global__ __launch_bounds__(128) void k_knn_refine(KnnArgs a, int kf, const flo
     }
     for (int c = 0; c < n; ++c) K[c] = exact_key(a, qr, I[c]);
     sort_pairs(K, I, n);
-    // error bound of a float32 key: d + 3 roundings of the dot product, the rounded norm, the final fma
+    // error bound of a stage-1 key = |t|^2 - 2 q.t: |error of q.t| <= gamma |q||t| (gamma from the host: the
+    // roundings of the accumulation, and the dropped cross products of the split operands), the norm
+    // rounded to float32 and the final fma; a quarter more for margin
     const double tmax = sqrt(__longlong_as_double((long long)*tmax_bits)), qs = sqrt(qn);
     const double u = 5.9604644775390625e-08;  // 2^-24
-    const double eps = 2.0 * (2.0 * (a.d + 4) * u * qs * tmax + 2.0 * u * (tmax * tmax + 2.0 * qs * tmax));
+    const double eps = 1.25 * (2.0 * gamma * qs * tmax + 2.0 * u * (tmax * tmax + 2.0 * qs * tmax));
     const bool complete = n < kf;  // fewer candidates than list entries: every train row is a candidate
     const bool proven = complete || (a.k <= n && K[a.k - 1] < (double)tau - eps);
     flag[q] = proven ? 0 : 1;
@@ -712,12 +751,12 @@ void plan_split(int64_t n_train, int64_t n_query, int *n_split, int64_t *rows_pe
 
 // ---- two-stage search: sizes ---------------------------------------------------------------------
 // candidates kept per query by the filter: k plus a margin for near-ties
-int filter_kf(int k) { return k + (k / 2 > 6 ? k / 2 : 6); }
-size_t filter_lds_bytes(int kf) { return (size_t)TT * LDT * 4 + (size_t)TT * 4 + (size_t)TQ * 4 + (size_t)TQ * kf * 8; }
+int filter_kf(int k) { return k + (k > 6 ? k : 6); }
+size_t filter_lds_bytes(int kf) { return (size_t)3 * TT * (DP + 8) * 2 + (size_t)TT * 4 + (size_t)TQ * 4 + (size_t)TQ * kf * 8; }
 // the filter pays off for small k (lists in LDS, two blocks per CU) and problems that fill the chip
 bool filter_eligible(int64_t n_train, int64_t n_query, int d, int k) {
     const int kf = filter_kf(k);
-    return d >= 1 && d <= DP && kf <= KF_MAX && kf <= n_train && filter_lds_bytes(kf) <= 64 * 1024 && n_train >= 4096 &&
+    return d >= 1 && d <= DP && kf <= KF_MAX && kf <= n_train && filter_lds_bytes(kf) <= 80 * 1024 && n_train >= 4096 &&
            n_query >= 64;
 }
 // split of the float64 search over the queries the proof rejects
@@ -832,8 +871,8 @@ int magic_knn_topk(int64_t n_train, int64_t n_query, int32_t d, int32_t k, const
         if (!filter_workspace(ar, n_train, n_query, k, &w)) return MAGIC_ERR_WORKSPACE;
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)k_knn_filter, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) !=
-                hipSuccess)
+            if (hipFuncSetAttribute((const void *)k_knn_filter_bf16, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    80 * 1024) != hipSuccess)
                 return MAGIC_ERR_RUNTIME;
             attr_set = true;
         }
@@ -847,10 +886,13 @@ int magic_knn_topk(int64_t n_train, int64_t n_query, int32_t d, int32_t k, const
         a.part_idx = nullptr;
         a.lds_lists = 1;
         dim3 fgrid((unsigned)(a.q_pad / TQ), (unsigned)a.n_split);
-        MAGIC_LAUNCH("knn_filter_f32_mfma", k_knn_filter, fgrid, 256, filter_lds_bytes(kf), stream, a, kf, w.fkey, w.fidx);
+        MAGIC_LAUNCH("knn_filter_bf16x6_mfma", k_knn_filter_bf16, fgrid, 256, filter_lds_bytes(kf), stream, a, kf, w.fkey,
+                     w.fidx);
+        // float32 accumulation of d products in 6 * d/16 matrix steps + the dropped cross products (2^-23 each)
+        const double gamma = ((double)d + 28.0) * 5.9604644775390625e-08 + 1.1920928955078125e-07;
         // stage 2: exact keys of the candidates, proof, output; rejected queries flagged
         MAGIC_LAUNCH("knn_refine", k_knn_refine, (unsigned)((n_query + 127) / 128), 128, 0, stream, a, kf, w.fkey, w.fidx,
-                     w.tmax, index_offset, dist, idx, w.flag);
+                     w.tmax, gamma, index_offset, dist, idx, w.flag);
         // rejected queries -> compact list, searched in float64
         {
             magic::ProfScope ps("knn_compact", stream);
