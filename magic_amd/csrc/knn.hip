@@ -398,14 +398,18 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
                 const float4 t4 = *reinterpret_cast<const float4 *>(tn + rt * 32 + 8 * g + 4 * hf);
                 tnr[4 * g + 0] = t4.x, tnr[4 * g + 1] = t4.y, tnr[4 * g + 2] = t4.z, tnr[4 * g + 3] = t4.w;
             }
+            // both query tiles side by side: two independent accumulator chains keep the matrix pipe fed
+            float16_t acc2[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[0][r] = acc2[1][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                magic::mfma_split6(acc2[0], af[s][0], af[s][1], af[s][2], bq[0][s][0], bq[0][s][1], bq[0][s][2]);
+                magic::mfma_split6(acc2[1], af[s][0], af[s][1], af[s][2], bq[1][s][0], bq[1][s][1], bq[1][s][2]);
+            }
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
-                float16_t acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    magic::mfma_split6(acc, af[s][0], af[s][1], af[s][2], bq[ct][s][0], bq[ct][s][1], bq[ct][s][2]);
+                const float16_t acc = acc2[ct];
                 const int ql = (2 * wave + ct) * 32 + lr;
                 const float th = thr[ql];
                 float key[16];
