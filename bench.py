@@ -149,7 +149,7 @@ def gather_ceiling_gbs(table_bytes):
 def _stage_collectives_through_host():
     """Rehearsal mode only: gloo on device tensors of two ranks sharing one GPU does not progress
     here, so the collectives this file and the package use take a host copy, exchange it, copy back."""
-    real = {k: getattr(dist, k) for k in ("all_reduce", "broadcast", "all_gather_into_tensor")}
+    real = {k: getattr(dist, k) for k in ("all_reduce", "broadcast", "all_gather_into_tensor", "all_to_all_single")}
 
     def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
         h = t.cpu()
@@ -165,7 +165,12 @@ def _stage_collectives_through_host():
         ho, h = out.cpu(), t.cpu()
         real["all_gather_into_tensor"](ho, h, group=group)
         out.copy_(ho)
+    def all_to_all_single(out, t, group=None):
+        ho, h = out.cpu(), t.cpu()
+        real["all_to_all_single"](ho, h, group=group)
+        out.copy_(ho)
     dist.all_reduce, dist.broadcast, dist.all_gather_into_tensor = all_reduce, broadcast, all_gather_into_tensor
+    dist.all_to_all_single = all_to_all_single
 
 
 def dense_work(n, n_dim, hidden, layers, n_pairs):
@@ -554,10 +559,14 @@ def knn_leg(args, world, rank, dev):
         if world > 1:
             nn_ = ShardedNearestNeighbors(k, device=dev)
             nn_.fit(x_local=xt, offset=lo)
-            rows = xt[mine_dev]
-            parts = [torch.empty(c, d, device=dev) for c in counts]
-            dist.all_gather(parts, rows)                          # 50,000 x 64 floats in all
-            sample_rows = torch.cat(parts)
+            # 50,000 x 64 floats in all; the ranks hold different numbers of the sampled rows, so every
+            # rank sends max(counts) rows (zero padded) in one equal-sized all-gather
+            cmax = max(counts)
+            rows = torch.zeros(cmax, d, device=dev)
+            rows[:counts[rank]] = xt[mine_dev]
+            gathered = torch.empty(world * cmax, d, device=dev)
+            dist.all_gather_into_tensor(gathered, rows)
+            sample_rows = torch.cat([gathered[r * cmax:r * cmax + counts[r]] for r in range(world)])
         else:
             nn_ = NearestNeighbors(k, device=dev).fit(xt)
             sample_rows = xt[mine_dev]
