@@ -252,7 +252,10 @@ def roofline_rows(prof, struct, workload, steps, n, n_dim, hidden, layers, n_pai
                         "frac": round(comp / sec / 1e9 / HBM_PEAK_GBS, 4),
                         "compulsory_bytes_per_launch": int(comp), "per_use_bytes_per_launch": int(per_use),
                         "per_use_rate_gbs": round(per_use / sec / 1e9, 1),
-                        "traffic": traffic, "wasted": round(traffic / comp, 3) if traffic else None})
+                        "traffic": traffic, "wasted": round(traffic / comp, 3) if traffic else None,
+                        # fabric bytes against the per-use count: < 1 when gathers hit the XCD's L2, > 1 when random
+                        # accesses move more than they use
+                        "traffic_over_per_use": round(traffic / per_use, 3) if traffic else None})
             if gath > 0:
                 ceil = gather_ceiling_gbs(table)
                 row["gather"] = {"table_bytes": int(table), "gathered_bytes_per_launch": int(gath),
