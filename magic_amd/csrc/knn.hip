@@ -340,9 +340,12 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
     }
     __syncthreads();
 
-    float4 pre[TT / 16];
-    float pre_tn = INFINITY;
-    auto fetch = [&](int64_t t0) {
+    // train tiles are requested two tiles ahead (two register buffers, used alternately): one tile of matrix
+    // work is shorter than a loaded memory system's latency
+    float4 preA[TT / 16], preB[TT / 16];
+    float tnA = INFINITY, tnB = INFINITY;
+    auto fetch = [&](int64_t t0, float4 (&pre)[TT / 16], float &pre_tn) {
+        if (t0 >= t_hi) return;
 #pragma unroll
         for (int i = 0; i < TT / 16; ++i) {
             const int r = (tid >> 4) + 16 * i;
@@ -367,8 +370,9 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
         bf16x2_t h[2];
         uint2 u;
     };
-    if (t_lo < t_hi) fetch(t_lo);
-    for (int64_t t0 = t_lo; t0 < t_hi; t0 += TT) {
+    fetch(t_lo, preA, tnA);
+    fetch(t_lo + TT, preB, tnB);
+    auto tile_step = [&](int64_t t0, float4 (&pre)[TT / 16], float &pre_tn) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TT / 16; ++i) {  // four consecutive k of one row -> 8 bytes in each plane
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
         }
         if (tid < TT) tn[tid] = pre_tn;
         __syncthreads();
-        if (t0 + TT < t_hi) fetch(t0 + TT);
+        fetch(t0 + 2 * TT, pre, pre_tn);
 
 #pragma unroll 1
         for (int rt = 0; rt < TT / 32; ++rt) {
@@ -392,43 +396,56 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
                     af[s][pl] = *reinterpret_cast<const bf16x8_t *>(tile + pl * BPLANE + (rt * 32 + lr) * BLD + 16 * s + 8 * hf);
-            float tnr[16];
+            // htn[r] = -|t|^2 / 2 of the 16 train rows this lane sees: key < th  <=>  acc + htn > -th / 2
+            float htn[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 t4 = *reinterpret_cast<const float4 *>(tn + rt * 32 + 8 * g + 4 * hf);
-                tnr[4 * g + 0] = t4.x, tnr[4 * g + 1] = t4.y, tnr[4 * g + 2] = t4.z, tnr[4 * g + 3] = t4.w;
+                htn[4 * g + 0] = -0.5f * t4.x, htn[4 * g + 1] = -0.5f * t4.y;
+                htn[4 * g + 2] = -0.5f * t4.z, htn[4 * g + 3] = -0.5f * t4.w;
             }
             // both query tiles side by side: two independent accumulator chains keep the matrix pipe fed
             float16_t acc2[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[0][r] = acc2[1][r] = 0.f;
+            // the six products of a step alternate between the two tiles: a matrix instruction that accumulates
+            // into the result of the one right before it waits for that result to be written back
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                magic::mfma_split6(acc2[0], af[s][0], af[s][1], af[s][2], bq[0][s][0], bq[0][s][1], bq[0][s][2]);
-                magic::mfma_split6(acc2[1], af[s][0], af[s][1], af[s][2], bq[1][s][0], bq[1][s][1], bq[1][s][2]);
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
+#pragma unroll
+                for (int p6 = 0; p6 < 6; ++p6) {
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][PA[p6]], bq[0][s][PB[p6]], acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][PA[p6]], bq[1][s][PB[p6]], acc2[1], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const float16_t acc = acc2[ct];
                 const int ql = (2 * wave + ct) * 32 + lr;
                 const float th = thr[ql];
-                float key[16];
-                bool any = false;
+                // cheap gate (16 adds, 8 three-way maxima): can any of the 16 keys be below the threshold?  The bar
+                // sits a little low (1e-6 |th|: more than the roundings that separate this form from the key
+                // below), so the gate never hides a candidate; the exact test follows inside.
+                float d[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    key[r] = fmaf(-2.f, acc[r], tnr[r]);
-                    any |= key[r] < th;
-                }
-                if (__any(any)) {
+                for (int r = 0; r < 16; ++r) d[r] = acc[r] + htn[r];
+                float m = fmaxf(fmaxf(d[0], d[1]), d[2]);
+#pragma unroll
+                for (int r = 3; r + 1 < 16; r += 2) m = fmaxf(fmaxf(m, d[r]), d[r + 1]);
+                m = fmaxf(m, d[15]);
+                const float bar = fmaf(-0.5f, th, -fabsf(th) * 1e-6f - 1e-30f);
+                if (__any(m > bar)) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        unsigned long long mask = __ballot(key[r] < th);
+                        const float key_r = fmaf(-2.f, acc[r], -2.f * htn[r]);
+                        unsigned long long mask = __ballot(key_r < th);
                         const int ti_mine = (int)(t0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf);
                         while (mask) {
                             const int srcl = __ffsll((long long)mask) - 1;
                             mask &= mask - 1;
                             const int q_ins = __shfl(ql, srcl, 64);
-                            const float kv = __shfl(key[r], srcl, 64);
+                            const float kv = __shfl(key_r, srcl, 64);
                             const int ti = __shfl(ti_mine, srcl, 64);
                             if (kv < thr[q_ins]) {
                                 float nt = wave_insert<false, float>(lkey + (size_t)q_ins * kf, lidx + (size_t)q_ins * kf, kf,
@@ -441,6 +458,10 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
                 }
             }
         }
+    };
+    for (int64_t t0 = t_lo; t0 < t_hi; t0 += 2 * TT) {
+        tile_step(t0, preA, tnA);
+        if (t0 + TT < t_hi) tile_step(t0 + TT, preB, tnB);
     }
     __syncthreads();
     float *gk = fkey + ((int64_t)split * a.q_pad + q_base) * kf;
