@@ -537,6 +537,7 @@ def knn_leg(args, world, rank, dev):
     from magic_amd import _lib
     from magic_amd.knn import ShardedNearestNeighbors, NearestNeighbors
     from magic_amd.model.eval import standardise_device
+    from magic_amd.parallel import gather_rows
     nt, nq, d, k = args.knn_train, args.knn_queries, 64, 10
     if args.scale != 1.0:
         nt, nq = max(4096, int(nt * args.scale)), max(512, int(nq * args.scale))
@@ -562,14 +563,8 @@ def knn_leg(args, world, rank, dev):
         if world > 1:
             nn_ = ShardedNearestNeighbors(k, device=dev)
             nn_.fit(x_local=xt, offset=lo)
-            # 50,000 x 64 floats in all; the ranks hold different numbers of the sampled rows, so every
-            # rank sends max(counts) rows (zero padded) in one equal-sized all-gather
-            cmax = max(counts)
-            rows = torch.zeros(cmax, d, device=dev)
-            rows[:counts[rank]] = xt[mine_dev]
-            gathered = torch.empty(world * cmax, d, device=dev)
-            dist.all_gather_into_tensor(gathered, rows)
-            sample_rows = torch.cat([gathered[r * cmax:r * cmax + counts[r]] for r in range(world)])
+            # 50,000 x 64 floats in all; the ranks hold different numbers of the sampled rows
+            sample_rows = gather_rows(xt[mine_dev], counts)
         else:
             nn_ = NearestNeighbors(k, device=dev).fit(xt)
             sample_rows = xt[mine_dev]

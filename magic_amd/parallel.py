@@ -91,3 +91,22 @@ def embed_graphs(embed_fn, graphs, out_width: int, device, group=None):
             dist.broadcast(emb, src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
         outs.append(emb)
     return outs
+
+
+def gather_rows(rows: torch.Tensor, counts, group=None) -> torch.Tensor:
+    """Concatenation, in rank order, of row blocks of different heights: rank r contributes ``counts[r]``
+    rows of ``rows`` (its first ``counts[r]``; the counts are known everywhere).  One equal-sized
+    all-gather of zero-padded blocks -- RCCL and gloo both want equal shares -- then the padding is cut."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = [int(c) for c in counts]
+    assert len(counts) == world and rows.shape[0] >= counts[rank]
+    if world == 1:
+        return rows[:counts[0]]
+    cmax = max(counts)
+    send = torch.zeros((cmax,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    send[:counts[rank]] = rows[:counts[rank]]
+    recv = torch.empty((world * cmax,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return torch.cat([recv[r * cmax:r * cmax + counts[r]] for r in range(world)])

@@ -207,6 +207,27 @@ def test_embedding_extraction_round_robin_world2(tmp_path):
         assert torch.equal(a, want) and torch.equal(b, want)
 
 
+def _gather_rows_worker(rank, world, port, out):
+    from magic_amd.parallel import gather_rows
+    _init(rank, world, port)
+    counts = [3, 5]
+    mine = torch.arange(counts[rank] * 4, dtype=torch.float32).reshape(counts[rank], 4) + 100 * rank
+    got = gather_rows(mine, counts)
+    torch.save(got, f"{out}/rows{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_gather_rows_of_different_heights_world2(tmp_path):
+    """Ranks that hold different numbers of rows (the sampled train rows of the sharded KNN scoring):
+    every rank ends with all rows in rank order, no padding left."""
+    port = _free_port()
+    mp.spawn(_gather_rows_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want = torch.cat([torch.arange(12, dtype=torch.float32).reshape(3, 4),
+                      torch.arange(20, dtype=torch.float32).reshape(5, 4) + 100])
+    for r in range(2):
+        assert torch.equal(torch.load(tmp_path / f"rows{r}.pt"), want)
+
+
 def test_bench_gpus_flag_starts_that_many_ranks():
     """`python bench.py --gpus 2` without a launcher must start two ranks itself (before touching a
     GPU) and report n_gpus = 2; --dry-run keeps the launch plumbing and drops the GPU work."""
