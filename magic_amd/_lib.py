@@ -103,7 +103,16 @@ def _check(status: int, what: str):
         raise MagicHipError(f"{what} failed: {msg} (status {status})")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """Handle of the current HIP stream of the current device.  The raw accessors cost a fraction of a
+    microsecond; ``torch.cuda.current_stream()`` builds a Python object per call (about 9 us, several
+    hundred times per training step)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
