@@ -268,6 +268,117 @@ __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
     }
 }
 
+// ---- source sweep, one wavefront per node (rows of 64 float4: H = 4, D = 64) ------------------------
+// With a whole wavefront on one node the per-edge scalars are loaded ONCE per node, lane = edge (light
+// segments have at most 64 edges): destination ids and edge types in one 256-byte load each, the
+// destinations' (et, lse) pairs in two gathers, the four attention weights of an edge by its own lane (four
+// exponentials per lane and node instead of one per lane and edge).  The weights go through a
+// wave-private LDS strip; the row loop takes the destination of edge k with v_readlane (scalar base
+// address) and double-buffers its batches of four rows, so nothing in it waits on anything but the rows
+// themselves.  The ids / types of the NEXT node are requested while this one runs.
+template <bool TABLE>
+__global__ __launch_bounds__(256) void k_bwd_src_wave(BwdArgs a) {
+    constexpr int H = 4, LPH = 16, SB = 4;
+    __shared__ float tbl[TABLE ? MAX_E_DIM * H : 1];
+    __shared__ __align__(16) float wls[4][64 * H];
+    stage_table<H, TABLE>(a, tbl);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane / LPH;
+    const bool writer = (lane % LPH) == 0;
+    float *wl = wls[wave];
+    const Walk wk = xcd_walk(a.pout, a.N, 4, wave);
+    const int stride = wk.stride;
+    const bool ordered = a.pout.order != nullptr;
+    const int last_pos = max(wk.end - 1, 0);
+    auto node_at = [&](int i) {
+        i = min(i, last_pos);
+        return ordered ? a.pout.order[i] : i;
+    };
+    auto edge_slot = [&](int b, int e) { return max(min(b + lane, e - 1), 0); };
+    int i0 = wk.pos;
+    int u0 = node_at(i0), u1 = node_at(i0 + stride), u2 = node_at(i0 + 2 * stride);
+    int b0 = a.pout.ptr[u0], e0 = a.pout.ptr[u0 + 1];
+    int b1 = a.pout.ptr[u1], e1 = a.pout.ptr[u1 + 1];
+    int idx = a.out_dst[edge_slot(b0, e0)];
+    int ty = TABLE ? a.etype[edge_slot(b0, e0)] : a.out_pos[edge_slot(b0, e0)];  // dense path: the CSC slot of ee
+    float4 hu = ld4_nt(a.hs + (int64_t)u0 * a.ld_hs + lane * 4);
+    float4 eh4 = ld4(a.eh + (int64_t)u0 * a.ld_s);
+    while (i0 < wk.end) {
+        const int deg = e0 - b0;
+        const bool light = deg <= a.pout.light_max;
+        // 1. per-edge scalars of this node (lane = edge): the destination's statistics
+        const float4 s01 = ld4(a.stat + (int64_t)idx * (2 * H)), s23 = ld4(a.stat + (int64_t)idx * (2 * H) + 4);
+        float4 eev;
+        if (TABLE)
+            eev = make_float4(tbl[ty * H + 0], tbl[ty * H + 1], tbl[ty * H + 2], tbl[ty * H + 3]);
+        else
+            eev = ld4(a.ee + (int64_t)ty * H);
+        // 2. first batch of rows
+        float4 rA[SB], rB[SB];
+        const int nb = light ? (deg + SB - 1) / SB : 0;  // batches of this node
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+            const int v = __builtin_amdgcn_readlane(idx, min(k, max(deg - 1, 0)));
+            rA[k] = ld4(a.d_pre + (int64_t)v * a.ld_dpre + lane * 4);
+        }
+        // 3. requests for the following nodes
+        const int nidx = a.out_dst[edge_slot(b1, e1)];
+        const int nty = TABLE ? a.etype[edge_slot(b1, e1)] : a.out_pos[edge_slot(b1, e1)];
+        const float4 nhu = ld4_nt(a.hs + (int64_t)u1 * a.ld_hs + lane * 4);
+        const float4 neh4 = ld4(a.eh + (int64_t)u1 * a.ld_s);
+        const int b2 = a.pout.ptr[u2], e2 = a.pout.ptr[u2 + 1];
+        const int u3 = node_at(i0 + 3 * stride);
+        // 4. attention weights of edge `lane`, all heads, into the strip
+        {
+            const float x0 = (eh4.x + eev.x) + s01.x, x1 = (eh4.y + eev.y) + s01.z;
+            const float x2 = (eh4.z + eev.z) + s23.x, x3 = (eh4.w + eev.w) + s23.z;
+            float4 pw;
+            pw.x = pack_attn(__expf(leaky(x0, a.slope) - s01.y), x0);
+            pw.y = pack_attn(__expf(leaky(x1, a.slope) - s01.w), x1);
+            pw.z = pack_attn(__expf(leaky(x2, a.slope) - s23.y), x2);
+            pw.w = pack_attn(__expf(leaky(x3, a.slope) - s23.w), x3);
+            __builtin_amdgcn_wave_barrier();  // the previous node's reads of the strip are done
+            *reinterpret_cast<float4 *>(wl + lane * H) = pw;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // 5. rows, two batches in flight
+        float4 acc = f4zero();
+        auto consume = [&](const float4 (&r)[SB], int j) {
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                const float pw = wl[min(j + k, 63) * H + h];
+                const float tt = head_sum<LPH>(dot4(r[k], hu));
+                if (j + k < deg) {
+                    if (writer) st2_nt(a.pairs + ((int64_t)(b0 + j + k) * H + h) * 2, pw, tt);
+                    fma4(acc, fabsf(pw), r[k]);
+                }
+            }
+        };
+        auto request = [&](float4 (&r)[SB], int j) {
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                const int v = __builtin_amdgcn_readlane(idx, min(j + k, max(deg - 1, 0)));
+                r[k] = ld4(a.d_pre + (int64_t)v * a.ld_dpre + lane * 4);
+            }
+        };
+        for (int bi = 0; bi < nb; bi += 2) {
+            if (bi + 1 < nb) request(rB, (bi + 1) * SB);
+            consume(rA, bi * SB);
+            if (bi + 1 < nb) {
+                if (bi + 2 < nb) request(rA, (bi + 2) * SB);
+                consume(rB, (bi + 1) * SB);
+            }
+        }
+        if (light) st4_nt(a.d_y + (int64_t)u0 * a.ld_dy + lane * 4, acc);
+        // 6. advance
+        u0 = u1, b0 = b1, e0 = e1;
+        u1 = u2, b1 = b2, e1 = e2;
+        u2 = u3;
+        idx = nidx, ty = nty, hu = nhu, eh4 = neh4;
+        i0 += stride;
+    }
+}
+
 template <int H, int LPH, bool TABLE>
 __global__ __launch_bounds__(256) void k_bwd_src_heavy1(BwdArgs a) {
     constexpr int G = H * LPH;
@@ -676,7 +787,10 @@ int launch_bwd(BwdArgs &a, hipStream_t stream) {
         int st0 = launch_table<H, LPH>(a, stream);
         return st0 != MAGIC_OK ? st0 : launch_status();
     }
-    MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_light<H, LPH, TABLE>), stride_grid(a.N, NPB, 256 * 16), 256, 0, stream, a);
+    if (H == 4 && LPH == 16)  // 1 KB rows: one wavefront per node
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_wave<TABLE>), stride_grid(a.N, 4, 256 * 5), 256, 0, stream, a);  // resident workgroups only: the pipeline fill is paid once per wavefront
+    else
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_light<H, LPH, TABLE>), stride_grid(a.N, NPB, 256 * 16), 256, 0, stream, a);
     if (a.pout.n_chunks > 0) {
         const int cgrid = chunk_grid(a.pout.n_chunks);
         MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_heavy1", H, LPH) : "gat_bwd_src_heavy1", (k_bwd_src_heavy1<H, LPH, TABLE>), cgrid, 256, 0, stream, a);
