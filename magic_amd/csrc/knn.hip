@@ -743,31 +743,26 @@ __global__ __launch_bounds__(256) void k_knn_merge(int64_t n_query, int k, int n
 
 bool mfma_path(int d) { return d >= 1 && d <= DP; }
 
-// The grid is (query blocks) x (train splits); 512 blocks are resident at once (256 CUs x 2).  With
-// few query blocks the train rows are split to fill the chip; with many, a split factor is chosen
-// so that the last round of resident blocks is nearly full (2,673 query blocks alone would leave the
-// sixth round 22 % occupied; split 4 ways they make 20.9 rounds).
+// The grid is (query blocks) x (train splits); 512 blocks are resident at once (256 CUs x 2) and run in
+// rounds.  With s splits a block sweeps 1/s of the train rows, so the search takes ceil(q s / 512) / s sweeps:
+// the split factor (at most 64: every split adds a list per query to merge) is the one that minimises that,
+// a finer split having to buy at least 2 %.  (2,673 query blocks alone would leave the sixth round 22 %
+// occupied; split 3 ways they make 15.7 rounds of 1/3.  196 query blocks split 3 ways take two rounds of 1/3,
+// split 5 ways two rounds of 1/5.)
 void plan_split(int64_t n_train, int64_t n_query, int *n_split, int64_t *rows_per_split) {
     const int64_t resident = 512;
-    int64_t qblocks = (n_query + TQ - 1) / TQ;
-    int64_t tiles = (n_train + TT - 1) / TT;
-    int64_t max_s = tiles / 8 > 0 ? tiles / 8 : 1;  // at least 8 tiles per split
+    const int64_t qblocks = (n_query + TQ - 1) / TQ;
+    const int64_t tiles = (n_train + TT - 1) / TT;
+    const int64_t max_s = tiles / 8 > 0 ? tiles / 8 : 1;  // at least 8 tiles per split
     int64_t s = 1;
-    if (qblocks < resident) {
-        s = (resident + qblocks - 1) / qblocks;
-        if (s > 64) s = 64;
-    } else {
-        double best = 0.0;
-        for (int64_t c = 1; c <= 8 && c <= max_s; ++c) {
-            const double rounds = (double)(qblocks * c) / (double)resident;
-            const double eff = rounds / (double)((qblocks * c + resident - 1) / resident);
-            if (eff > best + 0.02) {  // a finer split must buy at least 2 %
-                best = eff;
-                s = c;
-            }
+    double best = 1e300;
+    for (int64_t c = 1; c <= 64 && c <= max_s; ++c) {
+        const double sweeps = (double)((qblocks * c + resident - 1) / resident) / (double)c;
+        if (sweeps < best * 0.98) {
+            best = sweeps;
+            s = c;
         }
     }
-    if (s > max_s) s = max_s;
     int64_t tps = (tiles + s - 1) / s;
     s = (tiles + tps - 1) / tps;
     *n_split = (int)s;
