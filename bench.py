@@ -34,7 +34,6 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec
 F64_MFMA_PEAK_TF = 78.6    # MI355X fp64 matrix spec
 F32_MFMA_PEAK_TF = 157.3   # MI355X fp32 matrix spec
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X dense bf16 matrix peak (without structured sparsity)
-FWD_KIND = "fwd_unfused"    # byte model of the forward sweep (sweep_bytes)
 
 
 def parse():
@@ -94,26 +93,13 @@ def sweep_bytes(kind, N, E_seg, E_all, H, C, res):
     def once(per_edge_bytes):           # gathered table priced once when it stays cache resident
         return min(table, per_edge_bytes) if table <= CACHE_BYTES else per_edge_bytes
     if kind == "fwd":
-        # per edge: src id, edge type, attention weight out, gathered [hs | eh] row (row + one
-        #           64-byte sector for the H source scores stored behind it)
-        # per node: segment pointer, et, output row, residual row (+ 1-byte keep mask per element
-        #           when the residual is the dropped layer input)
-        g = E_seg * (row + 64)
-        table = N * (row + 64)
-        stream = E_seg * (8 + 4 * H) + N * (4 + 4 * H + row + (0 if res is None else row) + (C if res == "identity" else 0))
-        return stream + g, stream + (min(table, g) if table <= CACHE_BYTES else g), g, table
-    if kind == "fwd_unfused":
-        # per edge: src id, logit in, gathered hs row
-        # per node: segment pointer, walk order, (et, log-sum-exp) statistics out, output row, residual row
+        # per edge: src id, edge type, gathered hs row, gathered source scores (H floats of the [N,2H] score rows)
+        # per node: segment pointer, walk order, et, (et, log-sum-exp) statistics out, output row, residual row
         #           (+ 1-byte keep mask per element when the residual is the dropped layer input)
         g = E_seg * row
-        stream = E_seg * (4 + 4 * H) + N * (8 + 8 * H + row + (0 if res is None else row) + (C if res == "identity" else 0))
-        return stream + g, stream + once(g), g, table
-    if kind == "logits":
-        # per edge: src, dst, type ids, gathered eh[src] (H floats), logit out; per node: et once
-        g = E_all * 4 * H
-        stream = E_all * (12 + 4 * H) + N * 4 * H
-        return stream + g, stream + min(N * 4 * H, g), g, N * 4 * H
+        eh, eh_tab = E_seg * 4 * H, N * 4 * H
+        stream = E_seg * 8 + N * (8 + 12 * H + row + (0 if res is None else row) + (C if res == "identity" else 0))
+        return stream + g + eh, stream + once(g) + min(eh, eh_tab), g, table
     if kind == "bwd_src":
         # per edge: dst id, edge type, gathered gradient row, gathered (et, lse) of the destination,
         #           (a, t) pair out
@@ -225,7 +211,7 @@ def roofline_rows(prof, struct, workload, steps, n, n_dim, hidden, layers, n_pai
     sparse = {}     # template name -> list of (per_use, compulsory, gathered, table), one per launch of a step
     for H, C, r in lay:
         t = f"<{H},{C // (4 * H)}>"
-        for base, kind, e_seg in (("gat_fwd_light", FWD_KIND, e_in), ("gat_edge_logits", "logits", E),
+        for base, kind, e_seg in (("gat_fwd_light", "fwd", e_in),
                                   ("gat_bwd_src_light", "bwd_src", e_out), ("gat_bwd_dst_light", "bwd_dst", e_in),
                                   ("gat_bwd_deh_light", "bwd_deh", e_out)):
             sparse.setdefault(base + t, []).append(sweep_bytes(kind, n, e_seg, E, H, C, r))

@@ -173,6 +173,9 @@ int magic_proj_bwd_weight(int64_t n_rows, int32_t m, int32_t f,
  * stat [N,H,2] (optional, what magic_gat_bwd needs): per destination and head the pair
  * (et[v,h], max + log sum exp of the leaky-ReLU logits of v's in-edges), from which backward
  * recomputes a[e,h] = exp(leaky_relu(logit) - stat[v,h,1]).  Nodes without in-edges get (et, 0).
+ * The logits are formed inside the sweeps (staged in LDS per destination); only the edges of
+ * segments longer than the plan's light_max (at most 64) pass through the workspace.  in_dst is
+ * not read (the destination of a CSC segment is its node) and may be NULL.
  * ---------------------------------------------------------------------------------- */
 size_t magic_gat_fwd_workspace_bytes(int32_t n_edges, int32_t n_chunks, int32_t n_heads, int32_t head_dim);
 int magic_gat_fwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t head_dim,

@@ -851,6 +851,7 @@ int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     if (N == 0) return MAGIC_OK;
     const int C = H * D;
     if (!plan_valid(in_plan) || !plan_valid(out_plan) || !hs || !d_out || !d_pre || !d_y) return MAGIC_ERR_INVALID_ARG;
+    if (out_plan->light_max > 64) return MAGIC_ERR_UNSUPPORTED;  // lane = edge in the wavefront-per-node sweep
     const bool table = ee_table != nullptr;
     if (E > 0 && (!in_pos || !out_dst || !out_pos || !eh || !stat || ld_score < H)) return MAGIC_ERR_INVALID_ARG;
     if (E > 0 && table && !etype_csr) return MAGIC_ERR_INVALID_ARG;

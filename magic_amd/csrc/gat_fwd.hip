@@ -1,14 +1,14 @@
 // GAT layer, edge phase, forward: attention logits -> leaky ReLU -> per-destination
 // softmax -> weighted aggregation of source rows -> bias + residual (+ PReLU).
-// HBM-bound: per edge one gathered hs row (4*H*D bytes) dominates; everything else is
-// streamed in CSC order.  No atomics; every reduction has a fixed order.
+// HBM-bound: per edge one gathered hs row (4*H*D bytes) dominates, next to it the gather of the
+// source's H head scores; everything else is streamed in CSC order.  No atomics; every reduction
+// has a fixed order.  The logits x[e,:] = (eh[src e] + ee[e]) + et[dst e] are formed inside the
+// sweeps; only the edges of long segments pass through memory.
 //
 // Launch sequence per layer:
-//   gat_edge_logits       one thread per edge: x[e,:] = (eh[src e] + ee[e]) + et[dst e]
-//                         (the only place that gathers eh; fully edge-parallel)
-//   gat_fwd_light         one lane group per destination with <= light_max in-edges:
-//                         max / sum-exp over the streamed logits, then the row gather
-//   gat_fwd_heavy_*       longer segments in chunks of one wave each (stats, aggregate,
+//   gat_fwd_light         one lane group per destination with <= light_max in-edges: logits,
+//                         max / sum-exp and the row gather in one pass (logits staged in LDS)
+//   gat_fwd_heavy_*       longer segments in chunks of one wave each (logits + stats, aggregate,
 //                         finish), combined in chunk order
 #include "gat_common.h"
 
@@ -44,19 +44,33 @@ struct FwdArgs {
     float *ws_acc;    // [n_chunks,C]
 };
 
+constexpr int SEG = 64;  // longest segment a lane group takes (the plan's light_max may not exceed it)
+
+// Raw logit of CSC edge i (source u) under head h: (eh[u] + edge term) + et[v], the sum order of
+// model/gat.py:302-304 (u_add_v after the edge term joined the source score).
 template <int H, bool TABLE>
-__global__ __launch_bounds__(256) void k_edge_logits(FwdArgs a) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.E; i += gridDim.x * 256) {
-        const int u = a.src[i], v = a.dst[i];
-        const float *ehp = a.eh + (int64_t)u * a.ld_s;
-        const float *etp = a.et + (int64_t)v * a.ld_s;
-        const float *eep = TABLE ? a.ee_table + a.etype[i] * H : a.ee + (int64_t)i * H;
-        float r[H];
+__device__ __forceinline__ float edge_logit(const FwdArgs &a, int i, int u, int h, float etv) {
+    const float ee = TABLE ? a.ee_table[a.etype[i] * H + h] : a.ee[(int64_t)i * H + h];
+    return (a.eh[(int64_t)u * a.ld_s + h] + ee) + etv;
+}
+
+// sum / max over the G (aligned, all active) lanes of a node's group; every lane receives the same bits
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+    v = head_sum<(G < 16 ? G : 16)>(v);
 #pragma unroll
-        for (int h = 0; h < H; ++h) r[h] = (ehp[h] + eep[h]) + etp[h];
+    for (int off = 16; off < G; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <int G> __device__ __forceinline__ float group_max(float v) {
+    v = head_max<(G < 16 ? G : 16)>(v);
 #pragma unroll
-        for (int h = 0; h < H; ++h) a.x[(int64_t)i * H + h] = r[h];
-    }
+    for (int off = 16; off < G; off <<= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// attention weight w with the sign bit of the packed exponential (which carries "logit <= 0")
+__device__ __forceinline__ float sign_of(float w, float packed) {
+    return __uint_as_float(__float_as_uint(w) | (__float_as_uint(packed) & 0x80000000u));
 }
 
 template <int H, int LPH>
@@ -86,18 +100,31 @@ __device__ __forceinline__ void epilogue(const FwdArgs &a, int v, int g, float4 
     st4(a.out + (int64_t)v * a.ld_out + g * 4, acc);
 }
 
-// One lane group (G lanes) per destination node.  The LPH lanes of a head split the
-// segment for the max and the sum of exponentials (combined with DPP), then every lane
-// walks all edges for the aggregation of its 4 channels.
-template <int H, int LPH>
+// One group of W = max(G, 8) lanes per destination node; the logits are formed here and never touch HBM.
+// A row needs G lanes, so a group holds W/G sub-streams that take the edges round robin in the aggregation
+// (narrow decoder rows: 2 lanes per row, 4 edges at a time).
+//   <= 4 in-edges with one sub-stream (the common case of the wide layers): every lane forms its head's logit
+//     of each edge next to the row gather; one batch of clamped loads.
+//   otherwise: the W lanes take the edges round robin, lane = edge, all H heads: source id, edge type, the
+//     source's head scores -> logits into the group's LDS strip; group max; exponentials back into the strip
+//     (sign bit = "logit <= 0"); group sum; then the sub-streams walk the strip (weights by LDS broadcast,
+//     source ids from LDS) for the aggregation.  A logit is computed once.
+template <int H, int LPH, bool TABLE>
 __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
     constexpr int G = H * LPH;
-    constexpr int NPB = 256 / G;
-    const int g = threadIdx.x % G;
+    constexpr int W = G < 8 ? 8 : G;
+    constexpr int NSUB = W / G;
+    constexpr int NPB = 256 / W;
+    __shared__ float strip_w[NPB * SEG * H];
+    __shared__ int strip_u[NPB * SEG];
+    const int t = threadIdx.x % W;  // lane of the group: the edge it takes in the logit phase
+    const int g = t % G;            // float4 of the row
+    const int sub = t / G;
     const int h = g / LPH;
-    const int q = g % LPH;
-    const int slot = threadIdx.x / G;
-    const bool writer = q == 0;
+    const int slot = threadIdx.x / W;
+    const bool writer = (g % LPH) == 0;
+    float *ws = strip_w + slot * SEG * H;
+    int *us = strip_u + slot * SEG;
     const Walk wk = xcd_walk(a.plan, a.N, NPB, slot);
     for (int vi = wk.pos; vi < wk.end; vi += wk.stride) {
         // walk nodes by segment length when a node row is wide enough to stand alone in memory
@@ -105,17 +132,18 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
         const int b = a.plan.ptr[v], e = a.plan.ptr[v + 1];
         const int deg = e - b;
         if (deg > a.plan.light_max) continue;
+        const float etv = a.et[(int64_t)v * a.ld_s + h];
         float4 acc = f4zero();
         float lse = 0.f;
-        if (deg > 0 && deg <= 4) {
-            // short segment (the common case): one batch of clamped loads, one dependent chain
+        if (NSUB == 1 && deg > 0 && deg <= 4) {
             float x[4], l[4], p[4];
             float4 r[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ii = min(b + j, e - 1);
-                r[j] = ld4(a.hs + (int64_t)a.src[ii] * a.ld_hs + g * 4);
-                x[j] = a.x[(int64_t)ii * H + h];
+                const int u = a.src[ii];
+                r[j] = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
+                x[j] = edge_logit<H, TABLE>(a, ii, u, h, etv);
                 l[j] = leaky(x[j], a.slope);
             }
             float m = l[0];
@@ -138,74 +166,139 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
                     fma4(acc, w, r[j]);
                 }
             }
-        } else if (deg > 4) {
-            float m = -INFINITY;
-            for (int i = b + q; i < e; i += LPH) m = fmaxf(m, leaky(a.x[(int64_t)i * H + h], a.slope));
-            m = head_max<LPH>(m);
-            float s = 0.f;
-            for (int i = b + q; i < e; i += LPH) s += __expf(leaky(a.x[(int64_t)i * H + h], a.slope) - m);
-            s = head_sum<LPH>(s);
+        } else if (deg > 0) {
+            // lane = edge: logits of all heads into the strip, running max per head; two edges per trip so
+            // that their id -> score chains overlap
+            float et4[H], m4[H], s4[H];
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                et4[k] = a.et[(int64_t)v * a.ld_s + k];
+                m4[k] = -INFINITY;
+                s4[k] = 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();  // the previous node's reads of the strip are done
+            for (int k = t; k < deg; k += 2 * W) {
+                const int k2 = min(k + W, deg - 1);
+                const bool two = k + W < deg;
+                const int u1 = a.src[b + k], u2 = a.src[b + k2];
+                float x1[H], x2[H];
+#pragma unroll
+                for (int hh = 0; hh < H; ++hh) {
+                    x1[hh] = edge_logit<H, TABLE>(a, b + k, u1, hh, et4[hh]);
+                    x2[hh] = edge_logit<H, TABLE>(a, b + k2, u2, hh, et4[hh]);
+                }
+                us[k] = u1;
+#pragma unroll
+                for (int hh = 0; hh < H; ++hh) {
+                    ws[k * H + hh] = x1[hh];
+                    m4[hh] = fmaxf(m4[hh], leaky(x1[hh], a.slope));
+                }
+                if (two) {
+                    us[k2] = u2;
+#pragma unroll
+                    for (int hh = 0; hh < H; ++hh) {
+                        ws[k2 * H + hh] = x2[hh];
+                        m4[hh] = fmaxf(m4[hh], leaky(x2[hh], a.slope));
+                    }
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < H; ++hh) m4[hh] = group_max<W>(m4[hh]);
+            for (int k = t; k < deg; k += W) {
+#pragma unroll
+                for (int hh = 0; hh < H; ++hh) {
+                    const float x = ws[k * H + hh];
+                    const float p = __expf(leaky(x, a.slope) - m4[hh]);
+                    s4[hh] += p;
+                    ws[k * H + hh] = pack_attn(p, x);
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < H; ++hh) s4[hh] = group_sum<W>(s4[hh]);
+            float m = m4[0], s = s4[0];
+#pragma unroll
+            for (int k = 1; k < H; ++k)
+                if (h == k) {
+                    m = m4[k];
+                    s = s4[k];
+                }
             const float inv = 1.f / s;
             lse = m + logf(s);
-            int i = b;
-            for (; i + 4 <= e; i += 4) {
+            __builtin_amdgcn_wave_barrier();  // the strip is complete before anyone walks it
+            for (int k = sub; k < deg; k += 4 * NSUB) {
                 float4 r[4];
-                float w[4], x[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)a.src[i + j] * a.ld_hs + g * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x[j] = a.x[(int64_t)(i + j) * H + h];
+                float pw[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    w[j] = __expf(leaky(x[j], a.slope) - m) * inv;
-                    if (writer && a.attn) a.attn[(int64_t)(i + j) * H + h] = pack_attn(w[j], x[j]);
+                    const int kk = min(k + j * NSUB, deg - 1);
+                    r[j] = ld4(a.hs + (int64_t)us[kk] * a.ld_hs + g * 4);
+                    pw[j] = ws[kk * H + h];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fma4(acc, w[j], r[j]);
-            }
-            if (i < e) {  // tail of 1..3 edges: clamped batch so that the gathers overlap
-                float4 r[3];
-                float x[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int ii = min(i + j, e - 1);
-                    r[j] = ld4(a.hs + (int64_t)a.src[ii] * a.ld_hs + g * 4);
-                    x[j] = a.x[(int64_t)ii * H + h];
-                }
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    if (i + j < e) {
-                        const float w = __expf(leaky(x[j], a.slope) - m) * inv;
-                        if (writer && a.attn) a.attn[(int64_t)(i + j) * H + h] = pack_attn(w, x[j]);
+                for (int j = 0; j < 4; ++j) {
+                    if (k + j * NSUB < deg) {
+                        const float w = fabsf(pw[j]) * inv;
+                        if (writer && a.attn) a.attn[(int64_t)(b + k + j * NSUB) * H + h] = sign_of(w, pw[j]);
                         fma4(acc, w, r[j]);
                     }
                 }
             }
         }
-        if (writer && a.stat)
-            *reinterpret_cast<float2 *>(a.stat + ((int64_t)v * H + h) * 2) =
-                make_float2(a.et[(int64_t)v * a.ld_s + h], lse);
-        epilogue<H, LPH>(a, v, g, acc);
+        if (NSUB > 1) {  // sub-stream partials in a fixed order; sub-stream 0 keeps the sum
+#pragma unroll
+            for (int off = G; off < W; off <<= 1) {
+                acc.x += __shfl_xor(acc.x, off, 64);
+                acc.y += __shfl_xor(acc.y, off, 64);
+                acc.z += __shfl_xor(acc.z, off, 64);
+                acc.w += __shfl_xor(acc.w, off, 64);
+            }
+        }
+        if (sub == 0) {
+            if (writer && a.stat)
+                *reinterpret_cast<float2 *>(a.stat + ((int64_t)v * H + h) * 2) = make_float2(etv, lse);
+            epilogue<H, LPH>(a, v, g, acc);
+        }
     }
 }
 
-// Heavy segments, step 1: one wave per chunk, one lane per edge; per-chunk (max, sum exp)
-// for every head.
-template <int H>
+// Heavy segments, step 1: one wave per chunk, one lane per edge; forms the logits of the chunk's edges
+// (kept in x for step 2) and the per-chunk (max, sum exp) of every head.
+template <int H, bool TABLE>
 __global__ __launch_bounds__(256) void k_fwd_heavy_stats(FwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int c = xcd_chunk(threadIdx.x >> 6);
     if (c >= a.plan.n_chunks) return;
     const int beg = a.plan.chunk_beg[c], end = a.plan.chunk_end[c];
-    float m[H], s[H];
+    const int v = a.plan.heavy_node[a.plan.chunk_node[c]];
+    float m[H], s[H], etv[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         m[h] = -INFINITY;
         s[h] = 0.f;
+        etv[h] = a.et[(int64_t)v * a.ld_s + h];
     }
-    for (int i = beg + lane; i < end; i += 64) {
+    for (int i0 = beg + lane; i0 < end; i0 += 256) {  // four edges per lane and trip: their id -> score chains overlap
+        int ii[4], u[4];
+        float x[4][H];
 #pragma unroll
-        for (int h = 0; h < H; ++h) ms_fold(m[h], s[h], leaky(a.x[(int64_t)i * H + h], a.slope), 1.f);
+        for (int j = 0; j < 4; ++j) {
+            ii[j] = min(i0 + 64 * j, end - 1);
+            u[j] = a.src[ii[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h = 0; h < H; ++h) x[j][h] = edge_logit<H, TABLE>(a, ii[j], u[j], h, etv[h]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + 64 * j < end) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    a.x[(int64_t)ii[j] * H + h] = x[j][h];
+                    ms_fold(m[h], s[h], leaky(x[j][h], a.slope), 1.f);
+                }
+            }
+        }
     }
 #pragma unroll
     for (int h = 0; h < H; ++h) {
@@ -324,24 +417,17 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_finish(FwdArgs a) {
     }
 }
 
-template <int H, int LPH>
-int launch_fwd(const FwdArgs &a, bool table, hipStream_t stream) {
+template <int H, int LPH, bool TABLE>
+int launch_fwd(const FwdArgs &a, hipStream_t stream) {
     constexpr int G = H * LPH;
-    constexpr int NPB = 256 / G;
-    if (a.E > 0) {
-        int grid = stride_grid(a.E, 256, 256 * 32);
-        if (table)
-            MAGIC_LAUNCH(prof_on() ? prof_name("gat_edge_logits", H, LPH) : "gat_edge_logits", (k_edge_logits<H, true>), grid, 256, 0, stream, a);
-        else
-            MAGIC_LAUNCH(prof_on() ? prof_name("gat_edge_logits", H, LPH) : "gat_edge_logits", (k_edge_logits<H, false>), grid, 256, 0, stream, a);
-    }
+    constexpr int NPB = 256 / (G < 8 ? 8 : G);
     if (a.N > 0) {
         int grid = stride_grid(a.N, NPB, 256 * 32);
-        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_light", H, LPH) : "gat_fwd_light", (k_fwd_light<H, LPH>), grid, 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_light", H, LPH) : "gat_fwd_light", (k_fwd_light<H, LPH, TABLE>), grid, 256, 0, stream, a);
     }
     if (a.plan.n_chunks > 0) {
         int cgrid = chunk_grid(a.plan.n_chunks);
-        MAGIC_LAUNCH("gat_fwd_heavy_stats", (k_fwd_heavy_stats<H>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_heavy_stats", H, LPH) : "gat_fwd_heavy_stats", (k_fwd_heavy_stats<H, TABLE>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_heavy_agg", H, LPH) : "gat_fwd_heavy_agg", (k_fwd_heavy_agg<H, LPH>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_fwd_heavy_finish", (k_fwd_heavy_finish<H, LPH>), a.plan.n_heavy, 256, 0, stream, a);
     }
@@ -372,7 +458,8 @@ int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     if (!shape_supported(H, D)) return MAGIC_ERR_UNSUPPORTED;
     if (N == 0) return MAGIC_OK;
     if (!plan_valid(in_plan) || !hs || !eh || !et || !out) return MAGIC_ERR_INVALID_ARG;
-    if (E > 0 && (!in_src || !in_dst)) return MAGIC_ERR_INVALID_ARG;
+    if (E > 0 && !in_src) return MAGIC_ERR_INVALID_ARG;
+    if (in_plan->light_max > magic::SEG) return MAGIC_ERR_UNSUPPORTED;  // a lane group's strip holds SEG edges
     const bool table = ee_table != nullptr;
     if (E > 0 && table && !etype_csc) return MAGIC_ERR_INVALID_ARG;
     if (E > 0 && !table && !ee_csc) return MAGIC_ERR_INVALID_ARG;
@@ -416,7 +503,7 @@ int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     hipStream_t stream = (hipStream_t)stream_;
     const int lph = D / 4;
 #define X(h, l) \
-    if (H == h && lph == l) return launch_fwd<h, l>(a, table, stream);
+    if (H == h && lph == l) return table ? launch_fwd<h, l, true>(a, stream) : launch_fwd<h, l, false>(a, stream);
     MAGIC_GAT_SHAPES(X)
 #undef X
     return MAGIC_ERR_UNSUPPORTED;

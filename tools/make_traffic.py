@@ -17,8 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarise  # noqa: E402
 
 BENCH_NAME = {"k_fwd_light": "gat_fwd_light", "k_bwd_src_light": "gat_bwd_src_light",
-              "k_bwd_dst_light": "gat_bwd_dst_light", "k_bwd_deh_light": "gat_bwd_deh_light",
-              "k_edge_logits": "gat_edge_logits"}
+              "k_bwd_dst_light": "gat_bwd_dst_light", "k_bwd_deh_light": "gat_bwd_deh_light"}
 ROUND = os.environ.get("MAGIC_PROFILE_ROUND", "r02")
 
 
@@ -61,7 +60,7 @@ def main():
         base = k.split("<")[0]
         if base in BENCH_NAME and "<" in k:
             args = k.split("<", 1)[1].rstrip(">").replace(" ", "").split(",")
-            if len(args) == 1 or base == "k_edge_logits":      # templated on the head count only
+            if len(args) == 1:                                  # templated on the head count only
                 args = [args[0], lph_of.get(args[0], "?")]
             args = args[:2]                                     # (heads, lanes per head); drop further flags
             out[BENCH_NAME[base] + "<" + ",".join(args) + ">"] = int(v)
