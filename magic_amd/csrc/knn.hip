@@ -288,14 +288,17 @@ __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
 // accumulated in float32 (bf16_split.h): 6 x 32 cycles per 32x32x16 step against 4 x 4 x 32 cycles of
 // v_mfma_f32_16x16x4_f32 for the same products, 2.7 times the float32 matrix rate.  What is dropped
 // (2^-23 |q||t| per product) goes into the error bound of the proof in stage 2.
-// Block: 256 queries, wave w owns query tiles 2w and 2w+1 (32 queries each) with their split fragments
+// Block: 256 queries, wave w owns the query tiles 4w .. 4w+3 (16 queries each) with their split fragments
 // in registers for the whole sweep; the 64-row train tile is split while it is staged into LDS (three
 // planes of [64][72] bf16: the 16-byte fragment reads of 16 consecutive lanes cover all 64 banks once).
-// v_mfma_f32_32x32x16_bf16 (lane l): A[i = l&31][k = 8*(l>>5) ..+7], B[k = 8*(l>>5) ..+7][j = l&31],
-// D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31], r = 0..15.
+// The matrix instruction is v_mfma_f32_16x16x32_bf16: on random operands the chip holds a higher clock on
+// this shape than on 32x32x16 at the same cycles per product (measured: the sweep runs faster by the
+// clock ratio).  Lane l: A[i = l&15][k = 8*(l>>4) ..+7], B[k = 8*(l>>4) ..+7][j = l&15],
+// D[i = 4*(l>>4) + r][j = l&15], r = 0..3.
 constexpr int BLD = DP + 8;             // bf16 per staged train row
 constexpr int BPLANE = TT * BLD;        // bf16 per plane
 typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, float *fkey, int *fidx) {
     using magic::bf16x2_t;
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
     int *lidx = reinterpret_cast<int *>(lkey + (size_t)TQ * kf);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 31, hf = lane >> 5;
+    const int l16 = lane & 15, quad = lane >> 4;
     const int split = blockIdx.y;
     const int64_t q_base = (int64_t)blockIdx.x * TQ;
     const int64_t t_lo = (int64_t)split * a.rows_per_split;
@@ -321,21 +324,21 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
     }
     thr[tid] = INFINITY;
 
-    // query fragments: tile ct, K step s -> dims [16 s + 8 hf, +8) of query (2 wave + ct) * 32 + lr
-    bf16x8_t bq[2][4][3];
+    // query fragments: tile qt, K step s -> dims [32 s + 8 quad, +8) of query (4 wave + qt) * 16 + l16
+    bf16x8_t bq[4][2][3];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int64_t q = q_base + (2 * wave + ct) * 32 + lr;
+    for (int qt = 0; qt < 4; ++qt) {
+        const int64_t q = q_base + (4 * wave + qt) * 16 + l16;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 2; ++s) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int dj = 16 * s + 8 * hf + j;
+                const int dj = 32 * s + 8 * quad + j;
                 v[j] = (q < a.n_query && dj < a.d) ? a.query[q * a.ld_query + dj] : 0.f;
             }
-            magic::split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), bq[ct][s][0],
-                          bq[ct][s][1], bq[ct][s][2]);
+            magic::split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), bq[qt][s][0],
+                          bq[qt][s][1], bq[qt][s][2]);
         }
     }
     __syncthreads();
@@ -372,6 +375,16 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
     };
     fetch(t_lo, preA, tnA);
     fetch(t_lo + TT, preB, tnB);
+    // gate bars of this lane's four queries, refreshed after every insertion pass
+    float bar[4];
+    auto load_bars = [&]() {
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            const float th = thr[(4 * wave + qt) * 16 + l16];
+            bar[qt] = fmaf(-0.5f, th, -fabsf(th) * 1e-6f - 1e-30f);
+        }
+    };
+    load_bars();
     auto tile_step = [&](int64_t t0, float4 (&pre)[TT / 16], float &pre_tn) {
         __syncthreads();
 #pragma unroll
@@ -389,58 +402,50 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
         fetch(t0 + 2 * TT, pre, pre_tn);
 
 #pragma unroll 1
-        for (int rt = 0; rt < TT / 32; ++rt) {
-            bf16x8_t af[4][3];
+        for (int rt = 0; rt < TT / 16; ++rt) {
+            bf16x8_t af[2][3];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    af[s][pl] = *reinterpret_cast<const bf16x8_t *>(tile + pl * BPLANE + (rt * 32 + lr) * BLD + 16 * s + 8 * hf);
-            // htn[r] = -|t|^2 / 2 of the 16 train rows this lane sees: key < th  <=>  acc + htn > -th / 2
-            float htn[16];
+                    af[s][pl] = *reinterpret_cast<const bf16x8_t *>(tile + pl * BPLANE + (rt * 16 + l16) * BLD + 32 * s + 8 * quad);
+            // htn[r] = -|t|^2 / 2 of the 4 train rows this lane sees: key < th  <=>  acc + htn > -th / 2
+            const float4 t4 = *reinterpret_cast<const float4 *>(tn + rt * 16 + 4 * quad);
+            const float htn[4] = {-0.5f * t4.x, -0.5f * t4.y, -0.5f * t4.z, -0.5f * t4.w};
+            // the four query tiles side by side: consecutive matrix instructions never accumulate into the
+            // result of the one right before them
+            f32x4_t acc[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 t4 = *reinterpret_cast<const float4 *>(tn + rt * 32 + 8 * g + 4 * hf);
-                htn[4 * g + 0] = -0.5f * t4.x, htn[4 * g + 1] = -0.5f * t4.y;
-                htn[4 * g + 2] = -0.5f * t4.z, htn[4 * g + 3] = -0.5f * t4.w;
-            }
-            // both query tiles side by side: two independent accumulator chains keep the matrix pipe fed
-            float16_t acc2[2];
+            for (int qt = 0; qt < 4; ++qt) acc[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[0][r] = acc2[1][r] = 0.f;
-            // the six products of a step alternate between the two tiles: a matrix instruction that accumulates
-            // into the result of the one right before it waits for that result to be written back
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < 2; ++s) {
                 constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
 #pragma unroll
-                for (int p6 = 0; p6 < 6; ++p6) {
-                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][PA[p6]], bq[0][s][PB[p6]], acc2[0], 0, 0, 0);
-                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][PA[p6]], bq[1][s][PB[p6]], acc2[1], 0, 0, 0);
-                }
+                for (int p6 = 0; p6 < 6; ++p6)
+#pragma unroll
+                    for (int qt = 0; qt < 4; ++qt)
+                        acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][PA[p6]], bq[qt][s][PB[p6]], acc[qt], 0, 0, 0);
             }
+            // cheap gate (4 adds, 2 maxima per tile): can any of the keys be below its query's threshold?  The
+            // bar sits a little low (1e-6 |th|: more than the roundings that separate this form from the key
+            // below), so the gate never hides a candidate; the exact test follows inside.
+            bool hit = false;
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const float16_t acc = acc2[ct];
-                const int ql = (2 * wave + ct) * 32 + lr;
-                const float th = thr[ql];
-                // cheap gate (16 adds, 8 three-way maxima): can any of the 16 keys be below the threshold?  The bar
-                // sits a little low (1e-6 |th|: more than the roundings that separate this form from the key
-                // below), so the gate never hides a candidate; the exact test follows inside.
-                float d[16];
+            for (int qt = 0; qt < 4; ++qt) {
+                const float m = fmaxf(fmaxf(acc[qt][0] + htn[0], acc[qt][1] + htn[1]),
+                                      fmaxf(acc[qt][2] + htn[2], acc[qt][3] + htn[3]));
+                hit |= m > bar[qt];
+            }
+            if (__any(hit)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) d[r] = acc[r] + htn[r];
-                float m = fmaxf(fmaxf(d[0], d[1]), d[2]);
+                for (int qt = 0; qt < 4; ++qt) {
+                    const int ql = (4 * wave + qt) * 16 + l16;
+                    const float th = thr[ql];
 #pragma unroll
-                for (int r = 3; r + 1 < 16; r += 2) m = fmaxf(fmaxf(m, d[r]), d[r + 1]);
-                m = fmaxf(m, d[15]);
-                const float bar = fmaf(-0.5f, th, -fabsf(th) * 1e-6f - 1e-30f);
-                if (__any(m > bar)) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float key_r = fmaf(-2.f, acc[r], -2.f * htn[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        const float key_r = fmaf(-2.f, acc[qt][r], -2.f * htn[r]);
                         unsigned long long mask = __ballot(key_r < th);
-                        const int ti_mine = (int)(t0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf);
+                        const int ti_mine = (int)(t0 + rt * 16 + 4 * quad + r);
                         while (mask) {
                             const int srcl = __ffsll((long long)mask) - 1;
                             mask &= mask - 1;
@@ -456,6 +461,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
                         }
                     }
                 }
+                load_bars();  // this wave's insertions are the only writers of its queries' thresholds
             }
         }
     };
@@ -791,8 +797,14 @@ struct FilterWs {
     size_t cub_bytes;
     double *part_key;
     int *part_idx;
-    int ns_f, ns_x;
-    int64_t rps_f, rps_x, q_pad;
+    int ns_x;
+    int64_t rps_x, q_pad;
+    // stage 1 runs in up to two parts: whole rounds of resident blocks sweep all train rows unsplit (a split
+    // would build every query's list once per split: each list start inserts a few hundred candidates before
+    // its threshold bites), the remaining query blocks are split so that they fill the chip once more
+    int64_t q_main;  // queries of the unsplit part (a multiple of the resident blocks' queries, may be 0)
+    int ns_tail;
+    int64_t rps_tail;
 };
 
 size_t lds_bytes(int k, bool lds_lists) {
@@ -815,11 +827,21 @@ void plan_fallback(int64_t n_train, int64_t n_query, int *n_split, int64_t *rows
 // carve the two-stage workspace (after the train norms) out of `ar`; false when it does not fit
 bool filter_workspace(magic::Arena &ar, int64_t n_train, int64_t n_query, int k, FilterWs *w) {
     const int kf = filter_kf(k);
-    plan_split(n_train, n_query, &w->ns_f, &w->rps_f);
+    const int64_t resident = 512;  // 256 CUs x 2 blocks
+    const int64_t qblocks = (n_query + TQ - 1) / TQ;
+    w->q_main = qblocks / resident * resident * TQ;
+    w->ns_tail = 1;
+    w->rps_tail = 0;
+    size_t lists = (size_t)w->q_main;  // list slots (x kf) the larger part needs
+    if (n_query > w->q_main) {
+        plan_split(n_train, n_query - w->q_main, &w->ns_tail, &w->rps_tail);
+        const size_t tail = (size_t)w->ns_tail * (size_t)((n_query - w->q_main + TQ - 1) / TQ * TQ);
+        if (tail > lists) lists = tail;
+    }
     plan_fallback(n_train, n_query, &w->ns_x, &w->rps_x);
-    w->q_pad = (n_query + TQ - 1) / TQ * TQ;
-    w->fkey = ar.take<float>((size_t)w->ns_f * w->q_pad * kf);
-    w->fidx = ar.take<int>((size_t)w->ns_f * w->q_pad * kf);
+    w->q_pad = qblocks * TQ;
+    w->fkey = ar.take<float>(lists * kf);
+    w->fidx = ar.take<int>(lists * kf);
     w->tmax = ar.take<unsigned long long>(1);
     w->flag = ar.take<int>((size_t)w->q_pad);
     w->qmap = ar.take<int>((size_t)w->q_pad);
@@ -898,21 +920,30 @@ int magic_knn_topk(int64_t n_train, int64_t n_query, int32_t d, int32_t k, const
         }
         if (hipMemsetAsync(w.tmax, 0, sizeof(unsigned long long), stream) != hipSuccess) return MAGIC_ERR_RUNTIME;
         MAGIC_LAUNCH("knn_tmax", k_tmax, magic::stride_grid(n_train, 256 * 16, 1024), 256, 0, stream, n_train, tnorm, w.tmax);
-        // stage 1
-        a.q_pad = w.q_pad;
-        a.n_split = w.ns_f;
-        a.rows_per_split = w.rps_f;
+        // float32 accumulation of d products in 6 * d/16 matrix steps + the dropped cross products (2^-23 each)
+        const double gamma = ((double)d + 28.0) * 5.9604644775390625e-08 + 1.1920928955078125e-07;
         a.part_key = nullptr;
         a.part_idx = nullptr;
         a.lds_lists = 1;
-        dim3 fgrid((unsigned)(a.q_pad / TQ), (unsigned)a.n_split);
-        MAGIC_LAUNCH("knn_filter_bf16x6_mfma", k_knn_filter_bf16, fgrid, 256, filter_lds_bytes(kf), stream, a, kf, w.fkey,
-                     w.fidx);
-        // float32 accumulation of d products in 6 * d/16 matrix steps + the dropped cross products (2^-23 each)
-        const double gamma = ((double)d + 28.0) * 5.9604644775390625e-08 + 1.1920928955078125e-07;
-        // stage 2: exact keys of the candidates, proof, output; rejected queries flagged
-        MAGIC_LAUNCH("knn_refine", k_knn_refine, (unsigned)((n_query + 127) / 128), 128, 0, stream, a, kf, w.fkey, w.fidx,
-                     w.tmax, gamma, index_offset, dist, idx, w.flag);
+        // stage 1 (approximate candidates) and stage 2 (exact keys of the candidates, proof, output; rejected
+        // queries flagged) of the queries [q0, q0 + nq), train rows cut `ns` ways
+        auto two_stages = [&](int64_t q0, int64_t nq, int ns, int64_t rps) -> int {
+            KnnArgs b = a;
+            b.query = query + q0 * ld_query;
+            b.n_query = nq;
+            b.q_pad = (nq + TQ - 1) / TQ * TQ;
+            b.n_split = ns;
+            b.rows_per_split = rps;
+            dim3 fgrid((unsigned)(b.q_pad / TQ), (unsigned)ns);
+            MAGIC_LAUNCH("knn_filter_bf16x6_mfma", k_knn_filter_bf16, fgrid, 256, filter_lds_bytes(kf), stream, b, kf, w.fkey,
+                         w.fidx);
+            MAGIC_LAUNCH("knn_refine", k_knn_refine, (unsigned)((nq + 127) / 128), 128, 0, stream, b, kf, w.fkey, w.fidx,
+                         w.tmax, gamma, index_offset, dist + q0 * k, idx + q0 * k, w.flag + q0);
+            return MAGIC_OK;
+        };
+        if (w.q_main > 0) two_stages(0, w.q_main, 1, (n_train + TT - 1) / TT * TT);
+        if (n_query > w.q_main) two_stages(w.q_main, n_query - w.q_main, w.ns_tail, w.rps_tail);
+        a.q_pad = w.q_pad;
         // rejected queries -> compact list, searched in float64
         {
             magic::ProfScope ps("knn_compact", stream);

@@ -2,8 +2,9 @@
 // 1024-wide concatenation), where the projection is a GEMM bound by the matrix pipe rather than
 // a stream: Y[N,M] = (X (.) mask)[N,K] . op(W), K >= 96, M >= 128.
 //
-//  * 128 x 128 output tile per block of four waves (2 x 2, 64 x 64 per wave = 2 x 2 MFMA tiles),
-//    K in steps of 32.
+//  * 128 x 128 output tile per block of four waves (2 x 2, 64 x 64 per wave = 4 x 4 tiles of
+//    v_mfma_f32_16x16x32_bf16: on random operands the chip holds a higher clock on this shape than on
+//    32x32x16 at the same cycles per product), K in steps of 32 = one matrix instruction deep.
 //  * split-bf16 products (bf16_split.h).  The weight is split once per call by a small pre-pass
 //    into its three bf16 planes, stored tile by tile ([column block][K step][plane][128][32], zero
 //    padded) in the caller's workspace; the main kernel copies one 24 KB tile image per K step
@@ -37,7 +38,8 @@ constexpr size_t GEMM_LDS = (size_t)2 * 3 * PLANE * 2;
 constexpr int LDO = 64 + 4;        // strip row stride (floats)
 constexpr int TILE_ELEMS = 3 * GBN * GBK;  // bf16 per weight tile image in the workspace
 
-typedef float vec4_t __attribute__((ext_vector_type(4)));  // 16-byte register quad (plain vector: stays in VGPRs)
+typedef float vec4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));  // 16-byte register quad (plain vector: stays in VGPRs)
 
 struct GemmPlan {
     int col_blocks;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void k_proj_gemm(ProjArgs a, GemmPlan p) {
     __bf16 *sA = reinterpret_cast<__bf16 *>(smem);
     __bf16 *sB = sA + 3 * PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 31, hf = lane >> 5;
+    const int l16 = lane & 15, quad = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
     // consecutive block ids alternate over the 8 XCDs: give every XCD one contiguous range of tiles
     const int64_t pid = (int64_t)(blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
@@ -102,17 +104,17 @@ __global__ __launch_bounds__(256, 2) void k_proj_gemm(ProjArgs a, GemmPlan p) {
     const int64_t row0 = rb * GBM;
     const int colb = cb * GBN;
 
-    float16_t acc[2][2];
+    // lane l of a 16x16x32 step: A[i = l&15][k = 8*(l>>4) ..+7], B[k = 8*(l>>4) ..+7][j = l&15],
+    // D[i = 4*(l>>4) + r][j = l&15], r = 0..3
+    f32x4_t acc[4][4];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // column tiles of this wave that hold output columns at all (uniform per wave)
-    bool tile_ok[2];
+    bool tile_ok[4];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) tile_ok[ct] = colb + wc * 64 + ct * 32 < a.M;
+    for (int ct = 0; ct < 4; ++ct) tile_ok[ct] = colb + wc * 64 + ct * 16 < a.M;
 
     // staging roles: 8 threads per tile row (4 k each), 32 tile rows per pass, 4 passes
     const int sr = tid >> 3, sk = (tid & 7) * 4;
@@ -158,31 +160,28 @@ __global__ __launch_bounds__(256, 2) void k_proj_gemm(ProjArgs a, GemmPlan p) {
         }
     };
     auto mfma_step = [&]() {
+        bf16x8_t ap[4][3];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8_t ap[2][3], bp[2][3];
+        for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int pl = 0; pl < 3; ++pl)
+                ap[rt][pl] = *reinterpret_cast<const bf16x8_t *>(sA + pl * PLANE + (wr * 64 + rt * 16 + l16) * GLD + quad * 8);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            if (tile_ok[ct]) {
+                bf16x8_t bp[3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    ap[rt][pl] = *reinterpret_cast<const bf16x8_t *>(sA + pl * PLANE + (wr * 64 + rt * 32 + lr) * GLD +
-                                                                     s * 16 + hf * 8);
+                    bp[pl] = *reinterpret_cast<const bf16x8_t *>(sB + pl * PLANE + (wc * 64 + ct * 16 + l16) * GLD + quad * 8);
+                // the six kept products (bf16_split.h), smallest terms first; the four row tiles side by side so
+                // that consecutive matrix instructions never accumulate into the result of the one before
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-                if (tile_ok[ct]) {
+                for (int p6 = 0; p6 < 6; ++p6)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        bp[ct][pl] = *reinterpret_cast<const bf16x8_t *>(sB + pl * PLANE +
-                                                                         (wc * 64 + ct * 32 + lr) * GLD + s * 16 + hf * 8);
-                }
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-                if (tile_ok[ct]) {
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt)
-                        magic::mfma_split6(acc[rt][ct], ap[rt][0], ap[rt][1], ap[rt][2], bp[ct][0], bp[ct][1], bp[ct][2]);
-                }
-        }
+                    for (int rt = 0; rt < 4; ++rt)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[rt][PA[p6]], bp[PB[p6]], acc[rt][ct], 0, 0, 0);
+            }
     };
 
     // X tiles are prefetched two K steps ahead (HBM latency), W tiles one (they come out of L2)
@@ -221,29 +220,26 @@ __global__ __launch_bounds__(256, 2) void k_proj_gemm(ProjArgs a, GemmPlan p) {
     if (!EP) d = route(a, gc);
     if (tile_ok[0]) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 4; ++rt) {  // 16 rows x 64 columns through the strip
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                __builtin_amdgcn_wave_barrier();
+            for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8)
-                        os[((r8 & 3) + 8 * (r8 >> 2) + 4 * hf) * LDO + ct * 32 + lr] = acc[rt][ct][h * 8 + r8];
-                __builtin_amdgcn_wave_barrier();
+                for (int r = 0; r < 4; ++r) os[(4 * quad + r) * LDO + ct * 16 + l16] = acc[rt][ct][r];
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll 2
-                for (int i = 0; i < 4; ++i) {
-                    const int r = (lane >> 4) + 4 * i;
-                    const float4 q = *reinterpret_cast<const float4 *>(os + r * LDO + (lane & 15) * 4);
-                    const int64_t orow = row0 + wr * 64 + rt * 32 + h * SR + r;
-                    if (EP) {
-                        if (gc < a.C) epi_store4<true>(a, q, orow, gc, w, inv_w, cs4, dprelu);
-                    } else if (orow < a.n) {
-                        if (d.mode == 1) *reinterpret_cast<float4 *>(d.p + orow * d.ld) = q;
-                        if (d.mode == 2) route_store_elems(a, q, orow, gc);
-                    }
+            for (int i = 0; i < 4; ++i) {
+                const int r = (lane >> 4) + 4 * i;
+                const float4 q = *reinterpret_cast<const float4 *>(os + r * LDO + (lane & 15) * 4);
+                const int64_t orow = row0 + wr * 64 + rt * SR + r;
+                if (EP) {
+                    if (gc < a.C) epi_store4<true>(a, q, orow, gc, w, inv_w, cs4, dprelu);
+                } else if (orow < a.n) {
+                    if (d.mode == 1) *reinterpret_cast<float4 *>(d.p + orow * d.ld) = q;
+                    if (d.mode == 2) route_store_elems(a, q, orow, gc);
                 }
             }
+        }
     }
     if (EP && a.part_col) {
         // lanes l, l + 16, l + 32, l + 48 hold the same four columns

@@ -2,7 +2,7 @@
 """Time the sparse sweeps of one GAT layer (forward + backward edge phase) on a synthetic graph.
 
 Per-kernel microseconds from the library's own event brackets.  Run on the GPU box:
-    python tools/ubench/gat_sweeps.py theia|streamspot_batch [reps]
+    python tools/ubench/gat_sweeps.py theia|streamspot_batch [reps] [d_y row width in floats]
 Shapes timed: the encoder layer (H=4, D=hidden/4) and the decoder layer (H=1, D=8) of that workload.
 """
 import os
@@ -16,6 +16,7 @@ from magic_amd.synth import SHAPES, make_graph  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "theia"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+dy_width = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # 0: the model's packing (C + 2H rounded up to 4)
 dev = torch.device("cuda:0")
 n, e, n_dim, e_dim, hidden, _ = SHAPES["streamspot" if name == "streamspot_batch" else name]
 if name == "streamspot_batch":
@@ -46,7 +47,7 @@ def layer(H, D, with_act):
     res = torch.randn(N, C, device=dev) if with_act else None
     prelu = torch.full((1,), 0.25, device=dev) if with_act else None
     d_out = torch.randn(N, C, device=dev)
-    d_y = torch.empty(N, (C + 2 * H + 3) // 4 * 4, device=dev)
+    d_y = torch.empty(N, max(dy_width, (C + 2 * H + 3) // 4 * 4), device=dev)
 
     def once():
         out, pre, _, stat = ops.gat_fwd(s, H, D, hs, score[:, :H], score[:, H:], table, et_csc, None, 0.2, bias, res,
