@@ -250,11 +250,15 @@ def roofline_rows(prof, struct, workload, steps, n, n_dim, hidden, layers, n_pai
         elif name in dense:
             fl, by = dense[name]
             fl, by = fl / per_step, by / per_step
-            # a projection is matrix-bound when its flops per byte exceed the ridge of the fp32 matrix peak
-            if fl / by > F32_MFMA_PEAK_TF * 1e3 / HBM_PEAK_GBS:
+            # The projections form every fp32 product from six bf16 matrix products (split operands), so their
+            # matrix ceiling is the dense bf16 peak / 6; a launch is matrix-bound past the ridge of that ceiling.
+            split_peak = BF16_MFMA_PEAK_TF / 6.0
+            if fl / by > split_peak * 1e3 / HBM_PEAK_GBS:
                 ach = fl / sec / 1e12
-                row.update({"bound": "mfma", "achieved": round(ach, 1), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                            "frac": round(ach / F32_MFMA_PEAK_TF, 4), "algorithmic_flops_per_launch": int(fl),
+                row.update({"bound": "mfma", "achieved": round(ach, 1), "peak": round(split_peak, 1), "unit": "TFLOP/s",
+                            "frac": round(ach / split_peak, 4), "algorithmic_flops_per_launch": int(fl),
+                            "arithmetic": "fp32-grade products as 6 bf16 MFMA products (peak = dense bf16 peak / 6); "
+                                          "the fp32 matrix instruction peaks at %.1f" % F32_MFMA_PEAK_TF,
                             "traffic": None})
             else:
                 ach = by / sec / 1e9

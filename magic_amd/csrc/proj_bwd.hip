@@ -239,14 +239,15 @@ template <int MT, int FT> int run_dw(DwArgs &a, const DwPlan &p, hipStream_t str
 //  * a thread loads two consecutive rows of four columns as two float4 (coalesced 512-byte row
 //    segments), splits the four (row, row+1) pairs into bf16 planes and stores, per plane, four
 //    packed pairs with one 16-byte write into  tile[plane][row pair][column]  (conflict free);
-//  * a lane assembles its fragment (column c, rows 8h .. 8h+7) from the four row pairs 4h .. 4h+3
-//    at column c: four 4-byte reads (pairs of them fuse into ds_read2_b32), 136 words apart, so the
-//    two lane halves sit 32 banks apart and a wave covers all 64 banks once.
+//  * a lane of v_mfma_f32_16x16x32_bf16 (one 32-row step = one matrix instruction deep; the chip holds a
+//    higher clock on this shape than on 32x32x16) assembles its fragment (column c, rows 8q .. 8q+7,
+//    q = lane / 16) from the four row pairs 4q .. 4q+3 at column c: four 4-byte reads, 132 words apart,
+//    so the four lane quarters sit 16 banks apart and a wave covers all 64 banks once.
 // Row strips go to different blocks; the strip partials are added by a second launch in strip
 // order (bitwise reproducible).
 constexpr int WT = 128;            // tile edge
 constexpr int WK = 32;             // rows per step
-constexpr int WS = WT + 8;         // words per row pair of a plane
+constexpr int WS = WT + 4;         // words per row pair of a plane
 constexpr int WPLANE = (WK / 2) * WS;            // words per plane
 constexpr size_t WIDE_LDS = (size_t)2 * 3 * WPLANE * 4;
 
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void k_proj_dw_wide(WideArgs w) {
     unsigned int *sB = wsm + 3 * WPLANE;   // X tile
     const DwArgs &a = w.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 31, hf = lane >> 5;
+    const int l16 = lane & 15, quad = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
     const int strip = blockIdx.x, tile = blockIdx.y;
     const int m0 = (tile / w.f_blocks) * WT, f0 = (tile % w.f_blocks) * WT;
@@ -278,19 +279,18 @@ __global__ __launch_bounds__(256, 2) void k_proj_dw_wide(WideArgs w) {
     int64_t r_end = r_beg + w.rows_per_strip;
     if (r_end > a.n) r_end = a.n;
 
-    float16_t acc[2][2];
+    // lane l: A[i = l&15][k = 8*(l>>4) ..+7], B[k = 8*(l>>4) ..+7][j = l&15], D[i = 4*(l>>4) + r][j = l&15]
+    f32x4_t acc[4][4];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bool ok[4][4];  // MFMA tiles of this wave that hold output elements at all (uniform per wave)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
-    bool ok[2][2];  // MFMA tiles of this wave that hold output elements at all (uniform per wave)
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-            ok[rt][ct] = m0 + wr * 64 + rt * 32 < a.M && f0 + wc * 64 + ct * 32 < a.F;
+        for (int ct = 0; ct < 4; ++ct)
+            ok[rt][ct] = m0 + wr * 64 + rt * 16 < a.M && f0 + wc * 64 + ct * 16 < a.F;
 
     // staging role: four columns (c4) of both tiles, row pairs rp and rp + 8 of the step
     const int c4 = (tid & 31) * 4, rp = tid >> 5;
@@ -348,9 +348,9 @@ __global__ __launch_bounds__(256, 2) void k_proj_dw_wide(WideArgs w) {
             stage(sB, j, eb[0], eb[1]);
         }
     };
-    // fragment of column `col` (tile-relative), rows 16 s + 8 hf .. + 7: row pairs 8 s + 4 hf .. + 3
-    auto frag = [&](const unsigned int *plane, int col, int s_) {
-        const unsigned int *q = plane + (8 * s_ + 4 * hf) * WS + col;
+    // fragment of column `col` (tile-relative), rows 8 quad .. + 7 of the step: row pairs 4 quad .. + 3
+    auto frag = [&](const unsigned int *plane, int col) {
+        const unsigned int *q = plane + (4 * quad) * WS + col;
         union {
             u32x4_t u;
             magic::bf16x8_t h;
@@ -365,34 +365,38 @@ __global__ __launch_bounds__(256, 2) void k_proj_dw_wide(WideArgs w) {
         store_step(r);
         __syncthreads();
         if (r + WK < r_end) load_step(r + WK);
+        magic::bf16x8_t ap[4][3];
 #pragma unroll
-        for (int s_ = 0; s_ < 2; ++s_) {
-            magic::bf16x8_t ap[2][3], bp[2][3];
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int pl = 0; pl < 3; ++pl) ap[t][pl] = frag(sA + pl * WPLANE, wr * 64 + t * 16 + l16);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    ap[t][pl] = frag(sA + pl * WPLANE, wr * 64 + t * 32 + lr, s_);
-                    bp[t][pl] = frag(sB + pl * WPLANE, wc * 64 + t * 32 + lr, s_);
-                }
+        for (int ct = 0; ct < 4; ++ct) {
+            if (!ok[0][ct]) continue;
+            magic::bf16x8_t bp[3];
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int pl = 0; pl < 3; ++pl) bp[pl] = frag(sB + pl * WPLANE, wc * 64 + ct * 16 + l16);
+            // the six kept products (bf16_split.h), smallest terms first; row tiles side by side so that
+            // consecutive matrix instructions never accumulate into the result of the one before
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+            for (int p6 = 0; p6 < 6; ++p6)
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
                     if (ok[rt][ct])
-                        magic::mfma_split6(acc[rt][ct], ap[rt][0], ap[rt][1], ap[rt][2], bp[ct][0], bp[ct][1], bp[ct][2]);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[rt][PA[p6]], bp[PB[p6]], acc[rt][ct], 0, 0, 0);
         }
     }
     // strip partial of this tile, row-major [128][128]
     float *out = a.partial + ((int64_t)strip * gridDim.y + tile) * (WT * WT);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = wr * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                out[i * WT + wc * 64 + ct * 32 + lr] = acc[rt][ct][r];
+            for (int r = 0; r < 4; ++r) {
+                const int i = wr * 64 + rt * 16 + 4 * quad + r;
+                out[i * WT + wc * 64 + ct * 16 + l16] = acc[rt][ct][r];
             }
 }
 
