@@ -96,26 +96,30 @@ class _PairLinearFn(torch.autograd.Function):
     ``:75``), without forming the pair matrix: ``rows`` holds the P source rows then the P
     destination rows, and ``[s | d] W^T = s Wa^T + d Wb^T`` with ``W = [Wa | Wb]``.  Backward writes
     the two halves of the row gradient in place (autograd through slices and ``cat`` zero-fills and
-    adds full-size tensors); the weight gradient runs on the streaming dW kernel."""
+    adds full-size tensors).  All six products run on the library's projection kernels."""
 
     @staticmethod
     def forward(ctx, rows, n_pairs, w, b):
         width = rows.shape[1]
         ctx.n_pairs = n_pairs
-        ctx.save_for_backward(rows, w)
-        out = torch.addmm(b, rows[:n_pairs], w[:, :width].t())
-        return out.addmm_(rows[n_pairs:], w[:, width:].t())
+        wa, wb = w[:, :width].contiguous(), w[:, width:].contiguous()
+        ctx.save_for_backward(rows, wa, wb)
+        if n_pairs == 0:
+            return b.expand(0, w.shape[0]).clone()
+        out = ops.proj_fwd(rows[:n_pairs], wa, w.shape[0], 0, 0)[0]
+        return out.add_(ops.proj_fwd(rows[n_pairs:], wb, w.shape[0], 0, 0)[0]).add_(b)
 
     @staticmethod
     def backward(ctx, g):
-        rows, w = ctx.saved_tensors
-        n, width = ctx.n_pairs, rows.shape[1]
+        rows, wa, wb = ctx.saved_tensors
+        n = ctx.n_pairs
         g = g.contiguous()
         d_rows = d_w = d_b = None
         if ctx.needs_input_grad[0]:
             d_rows = torch.empty_like(rows)
-            torch.mm(g, w[:, :width], out=d_rows[:n])
-            torch.mm(g, w[:, width:], out=d_rows[n:])
+            if n:
+                ops.proj_bwd_input(g, wa, out=d_rows[:n])
+                ops.proj_bwd_input(g, wb, out=d_rows[n:])
         if ctx.needs_input_grad[2]:
             d_w = torch.cat([ops.proj_bwd_weight(g, rows[:n]), ops.proj_bwd_weight(g, rows[n:])], dim=1)
         if ctx.needs_input_grad[3]:
