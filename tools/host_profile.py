@@ -12,6 +12,27 @@ from magic_amd import synth  # noqa: E402
 from magic_amd.model.autoencoder import GMAEModel  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "streamspot_real"
+if name == "e2e":
+    # the reference's batch-level loop itself (model/train.py:18-48) on a batch of 12 StreamSpot-sized graphs
+    from magic_amd.model.train import batch_level_train
+    n, e, n_dim, e_dim, hidden, layers = synth.SHAPES["streamspot"]
+    dev = torch.device("cuda:0")
+    parts = [synth.make_graph(n, e, n_dim, e_dim, seed=1002 + i, attrs=False).to(dev) for i in range(12)]
+    for p_ in parts:
+        p_.structure.ensure_csr()
+    model = GMAEModel(n_dim, e_dim, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4, fused=True)
+    pool = [(p_, 0) for p_ in parts]
+    loader = [list(range(12))]
+    batch_level_train(model, pool, loader, opt, 3, dev, n_dim, e_dim, progress=False)
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    batch_level_train(model, pool, loader * 20, opt, 1, dev, n_dim, e_dim, progress=False)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(70)
+    sys.exit(0)
 n, e, n_dim, e_dim, hidden, layers = synth.SHAPES[name]
 dev = torch.device("cuda:0")
 torch.manual_seed(0)

@@ -58,6 +58,8 @@ def main():
             lph_of[args[0]] = args[1]
     for k, v in traffic.items():
         base = k.split("<")[0]
+        if base == "k_bwd_src_wave":    # the wavefront-per-node source sweep exists for 4 heads x 16 lanes only
+            out["gat_bwd_src_light<4,16>"] = int(v)
         if base in BENCH_NAME and "<" in k:
             args = k.split("<", 1)[1].rstrip(">").replace(" ", "").split(",")
             if len(args) == 1:                                  # templated on the head count only
