@@ -96,16 +96,21 @@ class _PairLinearFn(torch.autograd.Function):
     ``:75``), without forming the pair matrix: ``rows`` holds the P source rows then the P
     destination rows, and ``[s | d] W^T = s Wa^T + d Wb^T`` with ``W = [Wa | Wb]``.  Backward writes
     the two halves of the row gradient in place (autograd through slices and ``cat`` zero-fills and
-    adds full-size tensors).  All six products run on the library's projection kernels."""
+    adds full-size tensors).  The weight gradients run on the streaming dW kernel; with ``lib_gemm`` the
+    four other products run on the library's projection kernels (1.7 x the BLAS rate at hidden 256; on a
+    single small graph, where the step is bound by its launches, the six launches more measured no difference)."""
 
     @staticmethod
-    def forward(ctx, rows, n_pairs, w, b):
+    def forward(ctx, rows, n_pairs, w, b, lib_gemm):
         width = rows.shape[1]
         ctx.n_pairs = n_pairs
+        ctx.lib_gemm = lib_gemm = bool(lib_gemm) and n_pairs > 0
+        if not lib_gemm:
+            ctx.save_for_backward(rows, w[:, :width], w[:, width:])
+            out = torch.addmm(b, rows[:n_pairs], w[:, :width].t())
+            return out.addmm_(rows[n_pairs:], w[:, width:].t())
         wa, wb = w[:, :width].contiguous(), w[:, width:].contiguous()
         ctx.save_for_backward(rows, wa, wb)
-        if n_pairs == 0:
-            return b.expand(0, w.shape[0]).clone()
         out = ops.proj_fwd(rows[:n_pairs], wa, w.shape[0], 0, 0)[0]
         return out.add_(ops.proj_fwd(rows[n_pairs:], wb, w.shape[0], 0, 0)[0]).add_(b)
 
@@ -117,14 +122,17 @@ class _PairLinearFn(torch.autograd.Function):
         d_rows = d_w = d_b = None
         if ctx.needs_input_grad[0]:
             d_rows = torch.empty_like(rows)
-            if n:
+            if ctx.lib_gemm:
                 ops.proj_bwd_input(g, wa, out=d_rows[:n])
                 ops.proj_bwd_input(g, wb, out=d_rows[n:])
+            else:
+                torch.mm(g, wa, out=d_rows[:n])
+                torch.mm(g, wb, out=d_rows[n:])
         if ctx.needs_input_grad[2]:
             d_w = torch.cat([ops.proj_bwd_weight(g, rows[:n]), ops.proj_bwd_weight(g, rows[n:])], dim=1)
         if ctx.needs_input_grad[3]:
             d_b = g.sum(0)
-        return d_rows, None, d_w, d_b
+        return d_rows, None, d_w, d_b, None
 
 
 class GMAEModel(nn.Module):
@@ -252,13 +260,13 @@ class GMAEModel(nn.Module):
         return FusedCfg(g.structure.ensure_csr(), etype, g.edge_types_csr(), enc[0].edge_feat, len(enc), H, D, d.out_feat,
                         _pad_head_dim(d.out_feat), enc[0].leaky_relu.negative_slope, res_kinds, masks, scale)
 
-    def _edge_recon(self, rows, n_pairs):
+    def _edge_recon(self, rows, n_pairs, lib_gemm=False):
         """``edge_recon_fc`` (``model/autoencoder.py:75-78``) on the pairs (row i, row n_pairs + i) of
         ``rows``, with the weight gradients of its two linear layers on the streaming dW kernel (a
-        [rows, features] reduction over ~20k rows that the BLAS heuristics serve badly); the GEMMs
-        of forward and input gradient stay torch."""
+        [rows, features] reduction over ~20k rows that the BLAS heuristics serve badly) and, with
+        ``lib_gemm``, the first layer's forward and row-gradient products on the projection kernels."""
         fc1, act, fc2, sig = self.edge_recon_fc
-        h = act(_PairLinearFn.apply(rows, n_pairs, fc1.weight, fc1.bias))
+        h = act(_PairLinearFn.apply(rows, n_pairs, fc1.weight, fc1.bias, lib_gemm))
         return sig(_LinearFn.apply(h, fc2.weight, fc2.bias))
 
     def compute_loss(self, g: Graph, perm=None, pos_idx=None, neg_pairs=None, drop_masks=None, return_parts=False,
@@ -329,7 +337,7 @@ class GMAEModel(nn.Module):
             loss_sce = sce_loss_masked(recon_p, x_target, mask_nodes, self._alpha_l, n_dim=n_dim)
         loss = loss_sce
         # autoencoder.py:257-266: sampled edge reconstruction
-        y_pred = self._edge_recon(samples, n_pairs).squeeze(-1)
+        y_pred = self._edge_recon(samples, n_pairs, lib_gemm=samples.is_cuda).squeeze(-1)
         y = torch.cat([torch.ones(len(pos[0]), device=g.device), torch.zeros(len(neg[0]), device=g.device)])
         if neg_valid is None:
             loss_bce = self.recon_loss(y_pred, y)
