@@ -138,6 +138,35 @@ def test_knn_two_stage_search_is_exact(cuda, kind):
     assert torch.equal(mi, idx) and torch.equal(md, dist)
 
 
+def test_knn_unsplit_rounds_and_split_tail_agree(cuda):
+    """More than 131,072 queries: the first 512 query blocks sweep the train rows unsplit, the remaining
+    blocks are cut over the train rows.  Both parts must give what the same queries give when they are
+    searched in chunks small enough to take the split path only (that path is checked against the float64
+    oracle above), bit for bit, and a sample from each part is checked against the oracle directly.  A third
+    of the queries sit on rows that occur about 30 times, so the float64 sweep for rejected queries runs too."""
+    from magic_amd import _lib
+    rng = np.random.default_rng(23)
+    d, k, nt, nq = 24, 5, 9000, 131072 + 30000
+    centers = rng.standard_normal((30, d)).astype(np.float32)
+    base = centers[rng.integers(0, 30, 100)] + 0.05 * rng.standard_normal((100, d)).astype(np.float32)
+    train = centers[rng.integers(0, 30, nt)] + 0.05 * rng.standard_normal((nt, d)).astype(np.float32)
+    train[:3000] = base[rng.integers(0, 100, 3000)]
+    query = centers[rng.integers(0, 30, nq)] + 0.05 * rng.standard_normal((nq, d)).astype(np.float32)
+    dup = rng.random(nq) < 0.33
+    query[dup] = base[rng.integers(0, 100, int(dup.sum()))]
+    t, q = torch.from_numpy(train).to(cuda), torch.from_numpy(query).to(cuda)
+    dist, idx = _lib.knn_topk(t, q, k)
+    for lo in range(0, nq, 40000):
+        d_, i_ = _lib.knn_topk(t, q[lo:lo + 40000].contiguous(), k)
+        assert torch.equal(i_, idx[lo:lo + 40000]) and torch.equal(d_, dist[lo:lo + 40000]), lo
+    pick = np.concatenate([rng.integers(0, 131072, 300), rng.integers(131072, nq, 300)])
+    wd, wi = knn_oracle.exact_topk(train, query[pick], k, block=200)
+    got_d = dist.cpu().numpy()[pick]
+    assert np.abs(got_d - wd).max() < 1e-6
+    clear = ~dup[pick]                      # rows without exact ties: the ids are determined
+    assert np.array_equal(idx.cpu().numpy()[pick][clear], wi[clear])
+
+
 @pytest.mark.parametrize("n_dim,alpha,single", [(5, 3, False), (11, 3, True), (8, 2, False), (8, 1.5, True)])
 def test_sce_kernel(cuda, n_dim, alpha, single):
     from magic_amd.model.loss_func import sce_loss_masked
