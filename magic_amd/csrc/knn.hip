@@ -180,6 +180,11 @@ __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
     }
     __syncthreads();
 
+    // 16-query tiles of this wave that hold a query at all: the search of the few queries the proof rejected
+    // fills one or two tiles of a block, and the other waves only help staging the train tiles
+    const int64_t q_left = n_active - q_base - wave * 64;
+    const int nqb = q_left <= 0 ? 0 : (q_left >= 64 ? 4 : (int)((q_left + 15) / 16));
+
     // Software pipeline over the train tiles: the global loads of tile i+1 are issued into registers
     // before the matrix work on tile i and written to LDS after it, so their latency hides behind the
     // MFMAs instead of standing between two barriers.
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
         if (t0 + TT < t_hi) fetch(t0 + TT);
 
 #pragma unroll 1
-        for (int tb = 0; tb < TT / 16; ++tb) {
+        for (int tb = 0; tb < (nqb > 0 ? TT / 16 : 0); ++tb) {
             double af[16];
             {
                 const float *p = tile + (tb * 16 + (lane & 15)) * LDT + 16 * (lane >> 4);
@@ -236,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
             for (int r = 0; r < 4; ++r) tnr[r] = tn[tb * 16 + (lane >> 4) + 4 * r];
 #pragma unroll
             for (int qb = 0; qb < 4; ++qb) {
+                if (qb >= nqb) continue;  // uniform per wave: no query in this tile
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks)
@@ -559,6 +565,59 @@ __global__ __launch_bounds__(128) void k_knn_refine(KnnArgs a, int kf, const flo
         const double d2 = ok ? K[o] + qn : 0.0;
         dist[q * a.k + o] = ok ? sqrt(d2 > 0.0 ? d2 : 0.0) : (double)INFINITY;
         idx[q * a.k + o] = ok ? (int64_t)I[o] + index_offset : (int64_t)-1;
+    }
+}
+
+// Stage 2 for unsplit train rows (one list per query, kf <= 32): half a wavefront per query, lane = candidate.
+// Every lane forms the exact key of its candidate with the arithmetic of exact_key, the 32 (key, row) pairs
+// are ordered by a bitonic network of lane exchanges, and the proof and the outputs are those of
+// k_knn_refine (same tau, same eps, same order): the two kernels give identical results.
+__global__ __launch_bounds__(256) void k_knn_refine_one(KnnArgs a, int kf, const float *fkey, const int *fidx,
+                                                        const unsigned long long *tmax_bits, double gamma,
+                                                        int64_t index_offset, double *dist, int64_t *idx, int *flag) {
+    const int lane = threadIdx.x & 63, c = lane & 31;
+    const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
+    const bool qok = q < a.n_query;
+    const int64_t qc = qok ? q : a.n_query - 1;  // all lanes stay for the exchanges
+    const float *qr = a.query + qc * a.ld_query;
+    double qn = 0.0;
+    for (int j = 0; j < a.d; ++j) qn = fma((double)qr[j], (double)qr[j], qn);
+    const bool slot = c < kf;
+    const int ti = slot ? fidx[qc * kf + c] : kIdxNone;
+    const float approx = slot ? fkey[qc * kf + c] : INFINITY;
+    const bool valid = ti != kIdxNone;
+    const unsigned long long half = __ballot(valid) >> (lane & 32) & 0xffffffffull;
+    const int n = __popcll(half);
+    // the list is ascending: its last entry is the kf-th smallest approximate key
+    const float tau_full = __shfl(approx, (lane & 32) + kf - 1, 64);
+    const float tau = n == kf ? tau_full : INFINITY;
+    double K = valid ? exact_key(a, qr, ti) : (double)INFINITY;
+    int I = valid ? ti : INT32_MAX;
+#pragma unroll
+    for (int k2 = 2; k2 <= 32; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const double oK = __shfl_xor(K, j, 64);
+            const int oI = __shfl_xor(I, j, 64);
+            const bool up = (c & k2) == 0;           // this block of the network sorts ascending
+            const bool keep_min = ((c & j) == 0) == up;
+            const bool mine_less = K < oK || (K == oK && I < oI);
+            if (keep_min != mine_less) K = oK, I = oI;
+        }
+    }
+    const double tmax = sqrt(__longlong_as_double((long long)*tmax_bits)), qs = sqrt(qn);
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    const double eps = 1.25 * (2.0 * gamma * qs * tmax + 2.0 * u * (tmax * tmax + 2.0 * qs * tmax));
+    const double Kk = __shfl(K, (lane & 32) + a.k - 1, 64);
+    const bool complete = n < kf;
+    const bool proven = complete || (a.k <= n && Kk < (double)tau - eps);
+    if (!qok) return;
+    if (c == 0) flag[q] = proven ? 0 : 1;
+    if (c < a.k) {
+        const bool ok = c < n;
+        const double d2 = ok ? K + qn : 0.0;
+        dist[q * a.k + c] = ok ? sqrt(d2 > 0.0 ? d2 : 0.0) : (double)INFINITY;
+        idx[q * a.k + c] = ok ? (int64_t)I + index_offset : (int64_t)-1;
     }
 }
 
@@ -937,8 +996,12 @@ int magic_knn_topk(int64_t n_train, int64_t n_query, int32_t d, int32_t k, const
             dim3 fgrid((unsigned)(b.q_pad / TQ), (unsigned)ns);
             MAGIC_LAUNCH("knn_filter_bf16x6_mfma", k_knn_filter_bf16, fgrid, 256, filter_lds_bytes(kf), stream, b, kf, w.fkey,
                          w.fidx);
-            MAGIC_LAUNCH("knn_refine", k_knn_refine, (unsigned)((nq + 127) / 128), 128, 0, stream, b, kf, w.fkey, w.fidx,
-                         w.tmax, gamma, index_offset, dist + q0 * k, idx + q0 * k, w.flag + q0);
+            if (ns == 1 && kf <= 32 && k <= 32)
+                MAGIC_LAUNCH("knn_refine", k_knn_refine_one, (unsigned)((nq * 32 + 255) / 256), 256, 0, stream, b, kf, w.fkey,
+                             w.fidx, w.tmax, gamma, index_offset, dist + q0 * k, idx + q0 * k, w.flag + q0);
+            else
+                MAGIC_LAUNCH("knn_refine", k_knn_refine, (unsigned)((nq + 127) / 128), 128, 0, stream, b, kf, w.fkey, w.fidx,
+                             w.tmax, gamma, index_offset, dist + q0 * k, idx + q0 * k, w.flag + q0);
             return MAGIC_OK;
         };
         if (w.q_main > 0) two_stages(0, w.q_main, 1, (n_train + TT - 1) / TT * TT);
