@@ -809,11 +809,11 @@ __global__ __launch_bounds__(256) void k_knn_merge(int64_t n_query, int k, int n
 bool mfma_path(int d) { return d >= 1 && d <= DP; }
 
 // The grid is (query blocks) x (train splits); 512 blocks are resident at once (256 CUs x 2) and run in
-// rounds.  With s splits a block sweeps 1/s of the train rows, so the search takes ceil(q s / 512) / s sweeps:
-// the split factor (at most 64: every split adds a list per query to merge) is the one that minimises that,
-// a finer split having to buy at least 2 %.  (2,673 query blocks alone would leave the sixth round 22 %
-// occupied; split 3 ways they make 15.7 rounds of 1/3.  196 query blocks split 3 ways take two rounds of 1/3,
-// split 5 ways two rounds of 1/5.)
+// batches of that size.  With s splits a block sweeps 1/s of the train rows, so the search takes
+// ceil(q s / 512) / s sweeps: the split factor (at most 64: every split adds a list per query to merge) is the
+// one that minimises that, a finer split having to buy at least 2 %.  (196 query blocks split 3 ways take two
+// batches of 1/3, split 5 ways two batches of 1/5.)  Used for the float64 search and for the query blocks of
+// the two-stage search that do not fill a whole batch.
 void plan_split(int64_t n_train, int64_t n_query, int *n_split, int64_t *rows_per_split) {
     const int64_t resident = 512;
     const int64_t qblocks = (n_query + TQ - 1) / TQ;
