@@ -36,7 +36,8 @@ def batch_level_train(model, graphs, train_loader, optimizer, max_epoch, device,
         for it, batch in enumerate(train_loader):
             batch_g = [transform_graph(graphs[idx][0], n_dim, e_dim).to(device) for idx in batch]
             batch_g = batch_graphs(batch_g)                     # model/train.py:39
-            model.train()
+            if not model.training:                              # model/train.py:40 (a walk over ~60 modules per call)
+                model.train()
             loss = model(batch_g, **(step_hook(epoch, it, batch_g) or {})) if step_hook else model(batch_g)
             if grad_exchange is not None:
                 grad_exchange.zero()
