@@ -74,6 +74,41 @@ def test_gatconv_forward_backward(cuda, cfg):
         assert rel_err(pm.grad, po.grad) < TOL, k
 
 
+@pytest.mark.parametrize("in_dim,out_dim,heads", [(64, 16, 4), (256, 64, 4), (64, 8, 1), (64, 16, 1), (32, 8, 4)])
+def test_degree_ladder_every_segment_length_class(cuda, in_dim, out_dim, heads):
+    """In-degrees 0 .. 70 and a few hubs, one node each: the register path (<= 4 edges), the LDS strip with
+    one to several edges per lane, the sub-streams of narrow rows, the light / heavy boundary (64 / 65) and
+    chunked hubs (256 / 257 / 600), out-degrees spread alike.  Every ROW is compared, not the tensor's
+    maximum, so a wrong segment class cannot hide behind the others."""
+    degs = list(range(0, 71)) + [127, 128, 129, 255, 256, 257, 600]
+    n = 800
+    rng = np.random.default_rng(3)
+    dst = np.concatenate([np.full(d, v, np.int64) for v, d in enumerate(degs)])
+    src = np.concatenate([rng.choice(n, d, replace=False) for d in degs]).astype(np.int64)
+    ntype, etype = rng.integers(0, 4, n), rng.integers(0, 7, src.size)
+    og = to_ograph(src, dst, n, ntype, etype, 4, 7, torch.float64)
+    g = to_graph(src, dst, n, ntype, etype, 4, 7, cuda)
+    ref, mine = _layer_pair(in_dim, 7, out_dim, heads, heads > 1, heads > 1, 5, cuda)
+    torch.manual_seed(13)
+    x = torch.randn(n, in_dim)
+    xo, xm = x.double().requires_grad_(True), x.to(cuda).requires_grad_(True)
+    yo, ao = ref(og, xo, get_attention=True)
+    ym, am = mine(g, xm, get_attention=True)
+    scale = float(yo.detach().abs().max())
+    row_err = (ym.detach().double().cpu() - yo.detach()).abs().amax(1) / scale
+    assert float(row_err.max()) < TOL, int(row_err.argmax())
+    assert rel_err(am, ao) < TOL
+    w = torch.randn_like(yo)
+    (yo * w).sum().backward()
+    (ym * w.float().to(cuda)).sum().backward()
+    gscale = float(xo.grad.abs().max())
+    grow = (xm.grad.double().cpu() - xo.grad).abs().amax(1) / gscale
+    assert float(grow.max()) < TOL, int(grow.argmax())
+    for (k, po), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        if po.grad is not None:
+            assert rel_err(pm.grad, po.grad) < TOL, k
+
+
 def test_dense_edge_attr_path(cuda):
     """edata['attr'] that is not one-hot takes the dense per-edge score path."""
     n, e_dim = 300, 6
