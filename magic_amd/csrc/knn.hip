@@ -132,6 +132,39 @@ __device__ __forceinline__ KT wave_insert(KT *L, int *I, int k, KT kv, int ti, i
     return ld_rel<GLOBAL>(L + k - 1);
 }
 
+// value of lane `src` (wave-uniform) without a trip through the LDS crossbar
+__device__ __forceinline__ int lane_value(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ float lane_value(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// The same insertion for a float-keyed list of at most 64 entries in LDS: lane j holds entry j, so the
+// entries are read once, the lanes behind the insertion point store theirs one slot further, and the new
+// k-th key comes out of a lane read instead of another LDS read: one LDS round trip per insertion.
+__device__ __forceinline__ float wave_insert_lds(float *L, int *I, int k, float kv, int ti, int lane) {
+    const bool in = lane < k;
+    float v = kv;
+    int vi = ti;
+    if (in) {
+        v = L[lane];
+        vi = I[lane];
+    }
+    const bool before = in && ((v < kv) || (v == kv && vi < ti));
+    const int pos = __popcll(__ballot(before));
+    if (pos >= k) return lane_value(v, k - 1);
+    const float prev = lane_value(v, k >= 2 ? k - 2 : 0);
+    if (lane >= pos && lane + 1 < k) {
+        L[lane + 1] = v;
+        I[lane + 1] = vi;
+    }
+    if (lane == pos) {
+        L[pos] = kv;
+        I[pos] = ti;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return pos == k - 1 ? kv : prev;
+}
+
 template <bool GLOBAL>
 __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
     extern __shared__ __align__(16) char smem[];
@@ -381,16 +414,14 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
     };
     fetch(t_lo, preA, tnA);
     fetch(t_lo + TT, preB, tnB);
-    // gate bars of this lane's four queries, refreshed after every insertion pass
-    float bar[4];
-    auto load_bars = [&]() {
+    // thresholds (the k'-th key so far) of this lane's four queries and their gate bars: registers, replicated
+    // over the four lanes that hold rows of the same query; only this wave inserts for its queries
+    float thq[4], bar[4];
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-            const float th = thr[(4 * wave + qt) * 16 + l16];
-            bar[qt] = fmaf(-0.5f, th, -fabsf(th) * 1e-6f - 1e-30f);
-        }
-    };
-    load_bars();
+    for (int qt = 0; qt < 4; ++qt) {
+        thq[qt] = INFINITY;
+        bar[qt] = -INFINITY;
+    }
     auto tile_step = [&](int64_t t0, float4 (&pre)[TT / 16], float &pre_tn) {
         __syncthreads();
 #pragma unroll
@@ -407,8 +438,9 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
         __syncthreads();
         fetch(t0 + 2 * TT, pre, pre_tn);
 
-#pragma unroll 1
-        for (int rt = 0; rt < TT / 16; ++rt) {
+        // matrix work of 16 train rows against the wave's four query tiles (side by side: consecutive matrix
+        // instructions never accumulate into the result of the one right before them)
+        auto issue = [&](int rt, f32x4_t (&acc)[4], float (&htn)[4]) {
             bf16x8_t af[2][3];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -417,10 +449,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
                     af[s][pl] = *reinterpret_cast<const bf16x8_t *>(tile + pl * BPLANE + (rt * 16 + l16) * BLD + 32 * s + 8 * quad);
             // htn[r] = -|t|^2 / 2 of the 4 train rows this lane sees: key < th  <=>  acc + htn > -th / 2
             const float4 t4 = *reinterpret_cast<const float4 *>(tn + rt * 16 + 4 * quad);
-            const float htn[4] = {-0.5f * t4.x, -0.5f * t4.y, -0.5f * t4.z, -0.5f * t4.w};
-            // the four query tiles side by side: consecutive matrix instructions never accumulate into the
-            // result of the one right before them
-            f32x4_t acc[4];
+            htn[0] = -0.5f * t4.x, htn[1] = -0.5f * t4.y, htn[2] = -0.5f * t4.z, htn[3] = -0.5f * t4.w;
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) acc[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -432,6 +461,9 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
                     for (int qt = 0; qt < 4; ++qt)
                         acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][PA[p6]], bq[qt][s][PB[p6]], acc[qt], 0, 0, 0);
             }
+        };
+        // threshold test of 16 train rows and the insertions that pass it
+        auto gate = [&](int rt, const f32x4_t (&acc)[4], const float (&htn)[4]) {
             // cheap gate (4 adds, 2 maxima per tile): can any of the keys be below its query's threshold?  The
             // bar sits a little low (1e-6 |th|: more than the roundings that separate this form from the key
             // below), so the gate never hides a candidate; the exact test follows inside.
@@ -445,8 +477,10 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
             if (__any(hit)) {
 #pragma unroll
                 for (int qt = 0; qt < 4; ++qt) {
-                    const int ql = (4 * wave + qt) * 16 + l16;
-                    const float th = thr[ql];
+                    const float mq = fmaxf(fmaxf(acc[qt][0] + htn[0], acc[qt][1] + htn[1]),
+                                           fmaxf(acc[qt][2] + htn[2], acc[qt][3] + htn[3]));
+                    if (!__any(mq > bar[qt])) continue;  // this query tile holds no candidate
+                    float th = thq[qt];  // threshold of query (qt, l16), kept current through the insertions below
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float key_r = fmaf(-2.f, acc[qt][r], -2.f * htn[r]);
@@ -455,21 +489,36 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
                         while (mask) {
                             const int srcl = __ffsll((long long)mask) - 1;
                             mask &= mask - 1;
-                            const int q_ins = __shfl(ql, srcl, 64);
-                            const float kv = __shfl(key_r, srcl, 64);
-                            const int ti = __shfl(ti_mine, srcl, 64);
-                            if (kv < thr[q_ins]) {
-                                float nt = wave_insert<false, float>(lkey + (size_t)q_ins * kf, lidx + (size_t)q_ins * kf, kf,
-                                                                     kv, ti, lane);
-                                if (lane == 0) thr[q_ins] = nt;
-                                __builtin_amdgcn_wave_barrier();
+                            const float kv = lane_value(key_r, srcl);
+                            if (kv < lane_value(th, srcl)) {  // an earlier insertion may have tightened it
+                                const int ti = lane_value(ti_mine, srcl);
+                                const int q_ins = (4 * wave + qt) * 16 + (srcl & 15);
+                                const float nt = wave_insert_lds(lkey + (size_t)q_ins * kf, lidx + (size_t)q_ins * kf, kf, kv,
+                                                                 ti, lane);
+                                if (l16 == (srcl & 15)) th = nt;
                             }
                         }
                     }
+                    thq[qt] = th;
+                    bar[qt] = fmaf(-0.5f, th, -fabsf(th) * 1e-6f - 1e-30f);
                 }
-                load_bars();  // this wave's insertions are the only writers of its queries' thresholds
             }
+        };
+        // the test of row tile i runs behind the matrix instructions of row tile i + 1: its vector
+        // instructions read results that are complete instead of waiting for the matrix pipe to drain
+        f32x4_t accC[4], accN[4];
+        float htnC[4], htnN[4];
+        issue(0, accC, htnC);
+#pragma unroll 1
+        for (int rt = 0; rt + 1 < TT / 16; ++rt) {
+            issue(rt + 1, accN, htnN);
+            gate(rt, accC, htnC);
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) accC[qt] = accN[qt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) htnC[r] = htnN[r];
         }
+        gate(TT / 16 - 1, accC, htnC);
     };
     for (int64_t t0 = t_lo; t0 < t_hi; t0 += 2 * TT) {
         tile_step(t0, preA, tnA);
