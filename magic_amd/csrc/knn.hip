@@ -858,22 +858,30 @@ __global__ __launch_bounds__(256) void k_knn_merge(int64_t n_query, int k, int n
 bool mfma_path(int d) { return d >= 1 && d <= DP; }
 
 // The grid is (query blocks) x (train splits); 512 blocks are resident at once (256 CUs x 2) and run in
-// batches of that size.  With s splits a block sweeps 1/s of the train rows, so the search takes
-// ceil(q s / 512) / s sweeps: the split factor (at most 64: every split adds a list per query to merge) is the
-// one that minimises that, a finer split having to buy at least 2 %.  (196 query blocks split 3 ways take two
-// batches of 1/3, split 5 ways two batches of 1/5.)  Used for the float64 search and for the query blocks of
-// the two-stage search that do not fill a whole batch.
-void plan_split(int64_t n_train, int64_t n_query, int *n_split, int64_t *rows_per_split) {
+// batches of that size.  With s splits a block sweeps 1/s of the train rows, but every split starts each of
+// its queries' lists afresh, and a fresh list of L entries takes about L (1 + ln(rows / L)) insertions before
+// its threshold has settled.  Cost of a batch in swept-row equivalents: rows / s + g L (1 + ln(rows / (s L))),
+// g = what one insertion per query costs a block against sweeping one row (measured: 29 us against 68 ns in the
+// bf16 filter, about 430; about 150 in the slower float64 sweep); the split factor (at most 64: every split
+// adds a list per query to merge) minimises batches x that.  (196 query blocks against 2.6 M rows: 5 splits,
+// two batches of 1/5; against a 325,566-row shard: 2 splits, one batch of 1/2 -- thirteen splits would make
+// five batches of mostly list building.)  Used for the float64 search and for the query blocks of the
+// two-stage search that do not fill a whole batch.
+void plan_split(int64_t n_train, int64_t n_query, int list_len, double insert_cost, int *n_split,
+                int64_t *rows_per_split) {
     const int64_t resident = 512;
     const int64_t qblocks = (n_query + TQ - 1) / TQ;
     const int64_t tiles = (n_train + TT - 1) / TT;
     const int64_t max_s = tiles / 8 > 0 ? tiles / 8 : 1;  // at least 8 tiles per split
+    const double L = (double)(list_len > 0 ? list_len : 1);
     int64_t s = 1;
     double best = 1e300;
     for (int64_t c = 1; c <= 64 && c <= max_s; ++c) {
-        const double sweeps = (double)((qblocks * c + resident - 1) / resident) / (double)c;
-        if (sweeps < best * 0.98) {
-            best = sweeps;
+        const double rows = (double)n_train / (double)c;
+        const double fill = rows > L ? L * (1.0 + log(rows / L)) : rows;
+        const double cost = (double)((qblocks * c + resident - 1) / resident) * (rows + insert_cost * fill);
+        if (cost < best * 0.99) {  // a finer split has to buy at least 1 %
+            best = cost;
             s = c;
         }
     }
@@ -882,6 +890,7 @@ void plan_split(int64_t n_train, int64_t n_query, int *n_split, int64_t *rows_pe
     *n_split = (int)s;
     *rows_per_split = tps * TT;
 }
+constexpr double kInsertCostFilter = 430.0, kInsertCostF64 = 150.0;
 
 // ---- two-stage search: sizes ---------------------------------------------------------------------
 // candidates kept per query by the filter: k plus a margin for near-ties
@@ -942,7 +951,7 @@ bool filter_workspace(magic::Arena &ar, int64_t n_train, int64_t n_query, int k,
     w->rps_tail = 0;
     size_t lists = (size_t)w->q_main;  // list slots (x kf) the larger part needs
     if (n_query > w->q_main) {
-        plan_split(n_train, n_query - w->q_main, &w->ns_tail, &w->rps_tail);
+        plan_split(n_train, n_query - w->q_main, kf, kInsertCostFilter, &w->ns_tail, &w->rps_tail);
         const size_t tail = (size_t)w->ns_tail * (size_t)((n_query - w->q_main + TQ - 1) / TQ * TQ);
         if (tail > lists) lists = tail;
     }
@@ -980,7 +989,7 @@ size_t magic_knn_workspace_bytes(int64_t n_train, int64_t n_query, int32_t d, in
     if (mfma_path(d)) {
         int ns;
         int64_t rps;
-        plan_split(n_train, n_query, &ns, &rps);
+        plan_split(n_train, n_query, k, kInsertCostF64, &ns, &rps);
         size_t qpad = (size_t)((n_query + TQ - 1) / TQ) * TQ;
         b += magic::align_up((size_t)ns * qpad * k * 8) + magic::align_up((size_t)ns * qpad * k * 4);
     } else {
@@ -1081,7 +1090,7 @@ int magic_knn_topk(int64_t n_train, int64_t n_query, int32_t d, int32_t k, const
                      index_offset, dist, idx);
     } else if (mfma_path(d)) {
         if ((ld_train % 4) != 0 || ((uintptr_t)train % 16) != 0) return MAGIC_ERR_INVALID_ARG;  // float4 row loads
-        plan_split(n_train, n_query, &a.n_split, &a.rows_per_split);
+        plan_split(n_train, n_query, k, kInsertCostF64, &a.n_split, &a.rows_per_split);
         a.q_pad = (n_query + TQ - 1) / TQ * TQ;
         a.part_key = ar.take<double>((size_t)a.n_split * a.q_pad * k);
         a.part_idx = ar.take<int>((size_t)a.n_split * a.q_pad * k);
