@@ -474,6 +474,12 @@ __global__ __launch_bounds__(256, 2) void k_knn_filter_bf16(KnnArgs a, int kf, f
                                       fmaxf(acc[qt][2] + htn[2], acc[qt][3] + htn[3]));
                 hit |= m > bar[qt];
             }
+            // ask the scheduler to thread these vector instructions between the matrix instructions issued above
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
             if (__any(hit)) {
 #pragma unroll
                 for (int qt = 0; qt < 4; ++qt) {
