@@ -318,8 +318,9 @@ def gat_leg(args, workload, steps, warmup, world, rank, dev):
             # the reference's loop itself (model/train.py:18-48): per step transform_graph on the 12
             # graphs, batch, masking / sampling inside the model, backward, Adam -- nothing pre-generated
             from magic_amd.model.train import batch_level_train
+            # (mask permutation drawn on the device, as model/autoencoder.py:201 does for a model on the GPU)
             e2e_model = GMAEModel(n_dim, e_dim, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5,
-                                  "sce", 3).to(dev)
+                                  "sce", 3, mask_rng="device").to(dev)
             e2e_opt = torch.optim.Adam(e2e_model.parameters(), lr=1e-3, weight_decay=5e-4, fused=True)
             pool = [(p_, 0) for p_ in parts]
             loader = [list(range(batch_graphs))]

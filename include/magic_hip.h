@@ -322,6 +322,36 @@ int magic_readout(int64_t n_rows, int32_t width, const float *feat, int64_t ld_f
                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Union of device-resident component graphs: dgl.batch at model/train.py:39 (node ids and
+ * edge positions of component i shift by the node / edge counts of the components before
+ * it).  Integer work: results are bit-exact.
+ *
+ * magic_concat_offset runs a table of jobs {src, dst, len, add}: dst[i] = src[i] + add for
+ * i < len (src == NULL: dst[i] = add), all of one element width (4 or 8 bytes); the table
+ * (`n_jobs` x magic_concat_job, 32 bytes each) lives in DEVICE memory, `max_len` = the longest
+ * job.  One launch concatenates every index array of every component.
+ *
+ * magic_walk_order: for up to 4 segment arrays ptr[s] ([n_nodes[s] + 1], device) the walk
+ * order of the node-driven sweeps -- node ids cut into 8 contiguous ranges of equal work (per
+ * node: its edges when the segment has at most `light_max` of them, plus 2), inside a range by
+ * ascending segment-length class (0: empty, 1: 1-4 edges, then ceil(log2(length))), ties by
+ * node id -- into order[s] [n_nodes[s]] and the 9 range starts into xcd_start[s] (what
+ * magic_plan.node_order / xcd_start hold).  ptr / n_nodes / order / xcd_start are HOST arrays
+ * of n_arrays entries; every n_nodes[s] > 0.
+ * ---------------------------------------------------------------------------------- */
+typedef struct magic_concat_job {
+    const void *src;
+    void *dst;
+    int64_t len;
+    int64_t add;
+} magic_concat_job;
+int magic_concat_offset(int32_t elem_bytes, int32_t n_jobs, const void *jobs_device, int64_t max_len, void *stream);
+size_t magic_walk_order_workspace_bytes(int64_t total_nodes);
+int magic_walk_order(int32_t n_arrays, const int32_t *const *ptr, const int32_t *n_nodes, int32_t light_max,
+                     int32_t *const *order, int32_t *const *xcd_start, void *workspace, size_t workspace_bytes,
+                     void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Brute-force k nearest neighbours (Euclidean), replacing
  * sklearn.neighbors.NearestNeighbors(...).kneighbors at model/eval.py:154,158 and
  * :306,311.  Squared distances |q|^2 - 2 q.t + |t|^2 are formed in float64 on the f64

@@ -35,6 +35,10 @@ SYMBOLS = {
     "magic_prof_read": (c_i32, [c_i32, C.c_char_p, C.POINTER(c_i64), C.POINTER(C.c_double)]),
     "magic_csr_build_workspace_bytes": (c_i32, [c_i64, c_i64, C.POINTER(c_sz)]),
     "magic_csr_build": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "magic_concat_offset": (c_i32, [c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "magic_walk_order_workspace_bytes": (c_sz, [c_i64]),
+    "magic_walk_order": (c_i32, [c_i32, C.POINTER(c_vp), C.POINTER(c_i32), c_i32, C.POINTER(c_vp), C.POINTER(c_vp),
+                                 c_vp, c_sz, c_vp]),
     "magic_proj_fwd": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_i64,
                                c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "magic_proj_fwd_workspace_bytes": (c_sz, [c_i32, c_i32]),
@@ -184,6 +188,38 @@ def csr_build(src: torch.Tensor, dst: torch.Tensor, num_nodes: int):
                                _dev(in_ptr), _dev(in_src), _dev(in_eid), _dev(out_ptr), _dev(out_dst),
                                _dev(out_eid), ws.data_ptr(), ws.numel(), _stream()), "magic_csr_build")
     return in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid
+
+
+# ------------------------------------------------------------------------------------- union graphs
+def concat_offset(jobs: torch.Tensor, elem_bytes: int, device) -> None:
+    """``jobs``: CPU int64 tensor [n, 4] of (source address or 0, destination address, length, addend);
+    runs destination[i] = source[i] + addend for every job (one launch for all of them)."""
+    lib = load()
+    n = int(jobs.shape[0])
+    if n == 0:
+        return
+    # pinned + asynchronous: a pageable copy would make the host wait for everything queued so far
+    table = jobs.contiguous().pin_memory().to(device, non_blocking=True)
+    _check(lib.magic_concat_offset(int(elem_bytes), n, table.data_ptr(), int(jobs[:, 2].max()), _stream()),
+           "magic_concat_offset")
+
+
+def walk_order(ptrs, light_max: int):
+    """Walk order and XCD range starts of up to four device segment arrays (int32 ``ptr`` tensors with at
+    least one node each); returns [(order, xcd_start), ...]."""
+    lib = load()
+    k = len(ptrs)
+    dev = ptrs[0].device
+    ns = [int(p.numel()) - 1 for p in ptrs]
+    outs = [(torch.empty(n, dtype=torch.int32, device=dev), torch.empty(9, dtype=torch.int32, device=dev)) for n in ns]
+    ws = workspace(lib.magic_walk_order_workspace_bytes(sum(ns)), dev)
+    arr_p = (c_vp * k)(*[_dev(p, torch.int32, "ptr") for p in ptrs])
+    arr_n = (c_i32 * k)(*ns)
+    arr_o = (c_vp * k)(*[o.data_ptr() for o, _ in outs])
+    arr_x = (c_vp * k)(*[x.data_ptr() for _, x in outs])
+    _check(lib.magic_walk_order(k, arr_p, arr_n, int(light_max), arr_o, arr_x, ws.data_ptr(), ws.numel(), _stream()),
+           "magic_walk_order")
+    return outs
 
 
 def make_plan(plan, light_max: int) -> MagicPlan:

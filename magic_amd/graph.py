@@ -432,6 +432,84 @@ def _cat_plans(plans, ptr, n_off, e_off, offs: _Offsets) -> SegmentPlan:
                        chunk_end.to(i32), order=order, xcd_start=xcd_start)
 
 
+_STRUCT_I32 = ("in_src", "out_dst", "in_dst", "in_eid", "out_eid", "out_pos", "in_pos")
+_PLAN_I32 = ("heavy_node", "heavy_cptr", "chunk_node", "chunk_beg", "chunk_end")
+
+
+def _union_structure_device(graphs, n_off, e_off):
+    """Structure of the union of device-resident components that all carry their CSC / CSR arrays and segment
+    plans, assembled by the library: one job table and one launch per element width for every index array
+    (``magic_concat_offset``), one scan + sort for the two walk orders (``magic_walk_order``) -- about ten
+    launches instead of sixty.  Element for element what the tensor path below produces.  Returns None when
+    a component does not qualify (no CSR yet, unexpected dtype or layout)."""
+    from . import _lib
+    ss = [g._s for g in graphs]
+    i32, i64 = torch.int32, torch.int64
+    if not all(x.has_csr() and x.plan_in is not None and x.plan_out is not None for x in ss):
+        return None
+
+    def ok(t, dt):
+        return t.dtype == dt and t.is_contiguous() and t.is_cuda
+    for x in ss:
+        if not (ok(x.src, i64) and ok(x.dst, i64) and ok(x.in_ptr, i32) and ok(x.out_ptr, i32)):
+            return None
+        if not all(ok(getattr(x, a), i32) for a in _STRUCT_I32):
+            return None
+        for pl in (x.plan_in, x.plan_out):
+            if not all(ok(getattr(pl, a), i32) for a in _PLAN_I32):
+                return None
+    dev = ss[0].src.device
+    N, E = n_off[-1], e_off[-1]
+    jobs32, jobs64 = [], []
+
+    def new(n, dt=i32):
+        return torch.empty(n, dtype=dt, device=dev)
+
+    def add_jobs(jobs, out, parts, starts, adds, width):
+        base = out.data_ptr()
+        for t, st, ad in zip(parts, starts, adds):
+            n = t.numel() if t is not None else 1
+            if n:
+                jobs.append((t.data_ptr() if t is not None else 0, base + st * width, n, ad))
+
+    src, dst = new(E, i64), new(E, i64)
+    add_jobs(jobs64, src, [x.src for x in ss], e_off, n_off, 8)
+    add_jobs(jobs64, dst, [x.dst for x in ss], e_off, n_off, 8)
+    s = Structure(src, dst, N, checked=all(x._endpoints_ok for x in ss))
+    for a in ("in_ptr", "out_ptr"):          # [N + 1]: a leading 0, then every component's ptr[1:] + its edge offset
+        out = new(N + 1)
+        add_jobs(jobs32, out, [None], [0], [0], 4)
+        add_jobs(jobs32, out, [getattr(x, a)[1:] for x in ss], [1 + o for o in n_off], e_off, 4)
+        setattr(s, a, out)
+    for a in _STRUCT_I32:
+        out = new(E)
+        add_jobs(jobs32, out, [getattr(x, a) for x in ss], e_off, n_off if a in ("in_src", "out_dst", "in_dst") else e_off, 4)
+        setattr(s, a, out)
+    plans = {}
+    for name in ("plan_in", "plan_out"):
+        pls = [getattr(x, name) for x in ss]
+        h_off, c_off = [0], [0]
+        for pl in pls:
+            h_off.append(h_off[-1] + pl.n_heavy)
+            c_off.append(c_off[-1] + pl.n_chunks)
+        nh, nc = h_off[-1], c_off[-1]
+        heavy_node, heavy_cptr = new(nh), new(nh + 1 if nh else 1)
+        chunk_node, chunk_beg, chunk_end = new(nc), new(nc), new(nc)
+        add_jobs(jobs32, heavy_node, [pl.heavy_node for pl in pls], h_off, n_off, 4)
+        add_jobs(jobs32, heavy_cptr, [pl.heavy_cptr[:-1] for pl in pls], h_off, c_off, 4)
+        add_jobs(jobs32, heavy_cptr, [None], [nh], [nc], 4)          # closing entry (the single 0 without heavy nodes)
+        add_jobs(jobs32, chunk_node, [pl.chunk_node for pl in pls], c_off, h_off, 4)
+        add_jobs(jobs32, chunk_beg, [pl.chunk_beg for pl in pls], c_off, e_off, 4)
+        add_jobs(jobs32, chunk_end, [pl.chunk_end for pl in pls], c_off, e_off, 4)
+        plans[name] = (heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end)
+    _lib.concat_offset(torch.tensor(jobs64, dtype=i64).view(-1, 4), 8, dev)
+    _lib.concat_offset(torch.tensor(jobs32, dtype=i64).view(-1, 4), 4, dev)
+    (o_in, x_in), (o_out, x_out) = _lib.walk_order([s.in_ptr, s.out_ptr], LIGHT_MAX)
+    s.plan_in = SegmentPlan(s.in_ptr, *plans["plan_in"], order=o_in, xcd_start=x_in)
+    s.plan_out = SegmentPlan(s.out_ptr, *plans["plan_out"], order=o_out, xcd_start=x_out)
+    return s
+
+
 def batch(graphs: Sequence[Graph]) -> Graph:
     """Union graph with node-id offsets (``dgl.batch``, used at ``model/train.py:39``).
 
@@ -453,11 +531,13 @@ def batch(graphs: Sequence[Graph]) -> Graph:
 
     def cat(attr):
         return torch.cat([getattr(g._s, attr) for g in graphs])
-    node_off_per_edge64 = offs.vec(n_off[:-1], e_cnt, torch.int64)
-    src = cat("src") + node_off_per_edge64
-    dst = cat("dst") + node_off_per_edge64
-    s = Structure(src, dst, n_off[-1], checked=all(g._s._endpoints_ok for g in graphs))
-    if all(g._s.has_csr() for g in graphs):
+    s = _union_structure_device(graphs, n_off, e_off) if dev.type == "cuda" and n_off[-1] > 0 else None
+    if s is None:
+        node_off_per_edge64 = offs.vec(n_off[:-1], e_cnt, torch.int64)
+        src = cat("src") + node_off_per_edge64
+        dst = cat("dst") + node_off_per_edge64
+        s = Structure(src, dst, n_off[-1], checked=all(g._s._endpoints_ok for g in graphs))
+    if s.in_ptr is None and all(g._s.has_csr() for g in graphs):
         # no device synchronisation below: every size is already known on the host
         i32 = torch.int32
         node_off_per_edge = offs.vec(n_off[:-1], e_cnt)

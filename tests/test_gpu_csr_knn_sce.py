@@ -59,6 +59,56 @@ def test_batch_csr_equals_direct_sort(cuda):
             assert ta.dtype == tb.dtype and torch.equal(ta, tb), (which, name)
 
 
+def test_batch_by_the_library_equals_the_tensor_path(cuda, monkeypatch):
+    """The union graph assembled by the library (job-table concatenation, device walk order) against the
+    same union assembled with torch tensors: every array of the structure and of both segment plans, for
+    components with hubs, without edges, with a single node, and for a union without any heavy segment."""
+    import importlib
+    G = importlib.import_module("magic_amd.graph")
+    from magic_amd.graph import Graph, batch
+
+    def graphs(spec):
+        gs = []
+        for i, (n, e, hub_in, hub_out) in enumerate(spec):
+            if e:
+                src, dst, _, _ = small_graph(n, e, 4, 4, seed=300 + i, hub_deg=hub_in, hub_out=hub_out)
+                g = Graph(torch.from_numpy(src), torch.from_numpy(dst), n).to(cuda)
+            else:
+                g = Graph(torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), n).to(cuda)
+            g.structure.ensure_csr()
+            gs.append(g)
+        return gs
+
+    for spec in ([(300, 1500, 200, 120), (50, 0, 0, 0), (1, 0, 0, 0), (4000, 30000, 900, 700), (64, 64, 0, 0)],
+                 [(100, 150, 0, 0), (80, 100, 0, 0)],
+                 [(2000, 9000, 300, 0)]):
+        gs = graphs(spec)
+        calls = []
+        real = G._union_structure_device
+
+        def spy(*a, **k):
+            r = real(*a, **k)
+            calls.append(r is not None)
+            return r
+        monkeypatch.setattr(G, "_union_structure_device", spy)
+        lib = batch(gs).structure
+        assert calls == [True]
+        monkeypatch.setattr(G, "_union_structure_device", lambda *a, **k: None)
+        ref = batch(gs).structure
+        monkeypatch.setattr(G, "_union_structure_device", real)
+        assert lib.num_nodes == ref.num_nodes and lib.num_edges == ref.num_edges
+        for name in ("src", "dst", "in_ptr", "in_src", "in_eid", "in_dst", "out_ptr", "out_dst", "out_eid", "out_pos",
+                     "in_pos"):
+            ta, tb = getattr(lib, name), getattr(ref, name)
+            assert ta.dtype == tb.dtype and torch.equal(ta, tb), name
+        for which in ("plan_in", "plan_out"):
+            a, b = getattr(lib, which), getattr(ref, which)
+            assert (a.n_heavy, a.n_chunks) == (b.n_heavy, b.n_chunks)
+            for name in ("ptr", "heavy_node", "heavy_cptr", "chunk_node", "chunk_beg", "chunk_end", "order", "xcd_start"):
+                ta, tb = getattr(a, name), getattr(b, name)
+                assert ta.dtype == tb.dtype and torch.equal(ta, tb), (which, name)
+
+
 @pytest.mark.parametrize("nt,nq,d,k", [(5000, 777, 64, 10), (300, 130, 64, 10), (20000, 300, 64, 200),
                                         (400, 200, 256, 8), (100, 50, 2048, 2), (3000, 257, 32, 5)])
 def test_knn_matches_exact_oracle(cuda, nt, nq, d, k):
