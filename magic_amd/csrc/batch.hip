@@ -121,8 +121,9 @@ struct WalkWs {
 
 bool carve_walk(void *ws, size_t bytes, int32_t total_n, WalkWs *w) {
     size_t scan_b = 0, sort_b = 0;
-    hipcub::DeviceScan::InclusiveSum(nullptr, scan_b, (const int64_t *)nullptr, (int64_t *)nullptr, (int)total_n, nullptr);
-    hipcub::DeviceRadixSort::SortPairs(nullptr, sort_b, (const int32_t *)nullptr, (int32_t *)nullptr,
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_b, (const int64_t *)nullptr, (int64_t *)nullptr, (int)total_n,
+                                           nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_b, (const int32_t *)nullptr, (int32_t *)nullptr,
                                        (const int32_t *)nullptr, (int32_t *)nullptr, (int)total_n, 0, KEY_BITS, nullptr);
     w->cub_bytes = (scan_b > sort_b ? scan_b : sort_b) + 256;
     size_t off = 0;
