@@ -970,8 +970,9 @@ bool filter_workspace(magic::Arena &ar, int64_t n_train, int64_t n_query, int k,
     w->qmap = ar.take<int>((size_t)w->q_pad);
     w->qcount = ar.take<int>(1);
     w->cub_bytes = 0;
-    hipcub::DeviceSelect::Flagged(nullptr, w->cub_bytes, hipcub::CountingInputIterator<int>(0), (const int *)nullptr,
-                                  (int *)nullptr, (int *)nullptr, (int)n_query);
+    if (hipcub::DeviceSelect::Flagged(nullptr, w->cub_bytes, hipcub::CountingInputIterator<int>(0), (const int *)nullptr,
+                                      (int *)nullptr, (int *)nullptr, (int)n_query) != hipSuccess)
+        return false;
     w->cub = ar.take<char>(w->cub_bytes + 256);
     w->part_key = ar.take<double>((size_t)w->ns_x * w->q_pad * k);
     w->part_idx = ar.take<int>((size_t)w->ns_x * w->q_pad * k);
