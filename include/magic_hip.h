@@ -352,6 +352,23 @@ int magic_walk_order(int32_t n_arrays, const int32_t *const *ptr, const int32_t 
                      void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Acceptance test of uniformly drawn negative pairs: the rejection step of
+ * dgl.sampling.global_uniform_negative_sampling(g, k) as called at model/autoencoder.py:251
+ * (pairs that are neither edges of g nor self-loops, sampled without replacement).  Of the
+ * n_candidates pairs (cand_src[i], cand_dst[i]) (int64 node ids, device), taken in order,
+ * accept[i] = 1 for the first `num_samples` that are no edge, no self-loop and no repeat of an
+ * earlier candidate, 0 for all others (also for ids outside [0, n_nodes)).  The graph comes as
+ * both segment arrays (out_ptr/out_dst by source, in_ptr/in_src by destination, as
+ * magic_csr_build writes them); the shorter segment of a pair is scanned.  Integer work, one
+ * launch, nothing read back.  n_candidates <= MAGIC_NEGATIVE_FILTER_MAX.
+ * ---------------------------------------------------------------------------------- */
+#define MAGIC_NEGATIVE_FILTER_MAX 16384
+int magic_negative_filter(int64_t n_nodes, const int32_t *out_ptr, const int32_t *out_dst,
+                          const int32_t *in_ptr, const int32_t *in_src, int32_t n_candidates,
+                          const int64_t *cand_src, const int64_t *cand_dst, int32_t num_samples,
+                          uint8_t *accept /* [n_candidates] */, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Brute-force k nearest neighbours (Euclidean), replacing
  * sklearn.neighbors.NearestNeighbors(...).kneighbors at model/eval.py:154,158 and
  * :306,311.  Squared distances |q|^2 - 2 q.t + |t|^2 are formed in float64 on the f64

@@ -39,6 +39,7 @@ SYMBOLS = {
     "magic_walk_order_workspace_bytes": (c_sz, [c_i64]),
     "magic_walk_order": (c_i32, [c_i32, C.POINTER(c_vp), C.POINTER(c_i32), c_i32, C.POINTER(c_vp), C.POINTER(c_vp),
                                  c_vp, c_sz, c_vp]),
+    "magic_negative_filter": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "magic_proj_fwd": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_i64,
                                c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "magic_proj_fwd_workspace_bytes": (c_sz, [c_i32, c_i32]),
@@ -220,6 +221,25 @@ def walk_order(ptrs, light_max: int):
     _check(lib.magic_walk_order(k, arr_p, arr_n, int(light_max), arr_o, arr_x, ws.data_ptr(), ws.numel(), _stream()),
            "magic_walk_order")
     return outs
+
+
+NEGATIVE_FILTER_MAX = 16384  # MAGIC_NEGATIVE_FILTER_MAX
+
+
+def negative_filter(out_ptr: torch.Tensor, out_dst: torch.Tensor, in_ptr: torch.Tensor, in_src: torch.Tensor,
+                    u: torch.Tensor, v: torch.Tensor, num_samples: int) -> torch.Tensor:
+    """Bool mask over the candidate pairs (u[i], v[i]): in order, the first ``num_samples`` that are no edge
+    of the graph (given as its int32 segment arrays in both directions), no self-loop and no repeat."""
+    m = int(u.numel())
+    u = u.contiguous()
+    v = v.contiguous()
+    ok = torch.empty(m, dtype=torch.bool, device=u.device)
+    _check(load().magic_negative_filter(int(out_ptr.numel()) - 1, _dev(out_ptr, torch.int32, "out_ptr"),
+                                        _dev(out_dst, torch.int32, "out_dst"), _dev(in_ptr, torch.int32, "in_ptr"),
+                                        _dev(in_src, torch.int32, "in_src"), m, _dev(u, torch.int64, "u"),
+                                        _dev(v, torch.int64, "v"), int(num_samples), _dev(ok), _stream()),
+           "magic_negative_filter")
+    return ok
 
 
 def make_plan(plan, light_max: int) -> MagicPlan:

@@ -48,8 +48,8 @@ int bits_for(int64_t n) {
 }
 
 size_t sort_temp_bytes(int64_t E, int end_bit) {
-    size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr,
+    size_t bytes = 0;  // stays 0 if the query fails: the sort itself then reports the error
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr,
                                        (const int32_t *)nullptr, (int32_t *)nullptr, (int)E, 0, end_bit, nullptr);
     return bytes;
 }

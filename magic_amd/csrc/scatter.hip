@@ -102,8 +102,8 @@ int bits_for(int64_t n) {
 }
 
 size_t sort_temp_bytes(int64_t n, int end_bit) {
-    size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr,
+    size_t bytes = 0;  // stays 0 if the query fails: the sort itself then reports the error
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr,
                                        (const int32_t *)nullptr, (int32_t *)nullptr, (int)n, 0, end_bit);
     return bytes;
 }

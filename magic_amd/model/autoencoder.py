@@ -53,17 +53,11 @@ def negative_candidate_count(num_samples: int) -> int:
     return num_samples + (num_samples + 3) // 4
 
 
-def _negative_candidates(g: Graph, num_samples: int, generator: torch.Generator = None):
-    """Candidate (src, dst) pairs for ``dgl.sampling.global_uniform_negative_sampling(g, num_samples)``
-    (``model/autoencoder.py:251``) with fixed shapes, so that nothing is read back to the host:
-    ``negative_candidate_count(num_samples)`` uniformly drawn pairs and a mask that accepts, in draw
-    order, the first ``num_samples`` of them that are no edge of ``g``, no self-loop and no repeat of an
-    earlier accepted pair (DGL samples without replacement)."""
+def _accept_negatives(g: Graph, u: torch.Tensor, v: torch.Tensor, num_samples: int) -> torch.Tensor:
+    """Mask that accepts, in order, the first ``num_samples`` candidate pairs that are no edge of ``g``, no
+    self-loop and no repeat of an earlier candidate -- with tensor operations (any device)."""
     n = g.num_nodes()
-    dev = g.device
-    m = negative_candidate_count(num_samples)
-    u = torch.randint(0, n, (m,), device=dev, generator=generator)
-    v = torch.randint(0, n, (m,), device=dev, generator=generator)
+    m = u.numel()
     ekey = _sorted_edge_keys(g)
     key = u * n + v
     pos = torch.searchsorted(ekey, key).clamp_(max=max(ekey.numel() - 1, 0))
@@ -71,13 +65,32 @@ def _negative_candidates(g: Graph, num_samples: int, generator: torch.Generator 
     ok = (u != v) & ~is_edge
     # repeats: stable sort by key, every element but the first of a run of equal keys is a repeat
     skey, order = torch.sort(key, stable=True)
-    repeat_sorted = torch.zeros(m, dtype=torch.bool, device=dev)
+    repeat_sorted = torch.zeros(m, dtype=torch.bool, device=u.device)
     repeat_sorted[1:] = skey[1:] == skey[:-1]
     repeat = torch.empty_like(repeat_sorted)
     repeat[order] = repeat_sorted
     ok &= ~repeat
     ok &= torch.cumsum(ok, 0) <= num_samples
-    return u, v, ok
+    return ok
+
+
+def _negative_candidates(g: Graph, num_samples: int, generator: torch.Generator = None):
+    """Candidate (src, dst) pairs for ``dgl.sampling.global_uniform_negative_sampling(g, num_samples)``
+    (``model/autoencoder.py:251``) with fixed shapes, so that nothing is read back to the host:
+    ``negative_candidate_count(num_samples)`` uniformly drawn pairs and a mask that accepts, in draw
+    order, the first ``num_samples`` of them that are no edge of ``g``, no self-loop and no repeat of an
+    earlier accepted pair (DGL samples without replacement).  On the GPU the mask is one launch of the
+    library (``magic_negative_filter``: segment scans and an LDS table instead of an edge-key sort, a
+    search and a sort of the candidates)."""
+    n = g.num_nodes()
+    dev = g.device
+    m = negative_candidate_count(num_samples)
+    u = torch.randint(0, n, (m,), device=dev, generator=generator)
+    v = torch.randint(0, n, (m,), device=dev, generator=generator)
+    if dev.type == "cuda" and m <= _lib.NEGATIVE_FILTER_MAX:
+        s = g.structure.ensure_csr()
+        return u, v, torch.ops.magic.negative_filter(s.out_ptr, s.out_dst, s.in_ptr, s.in_src, u, v, num_samples)
+    return u, v, _accept_negatives(g, u, v, num_samples)
 
 
 def global_uniform_negative_sampling(g: Graph, num_samples: int, generator: torch.Generator = None):

@@ -75,6 +75,13 @@ _register("csr_build", "(Tensor src, Tensor dst, int num_nodes) -> (Tensor, Tens
           _csr_build, _csr_build_fake)
 
 
+_register("negative_filter", "(Tensor out_ptr, Tensor out_dst, Tensor in_ptr, Tensor in_src, Tensor u, Tensor v, "
+          "int num_samples) -> Tensor",
+          lambda out_ptr, out_dst, in_ptr, in_src, u, v, num_samples:
+          _lib.negative_filter(out_ptr, out_dst, in_ptr, in_src, u, v, num_samples),
+          lambda out_ptr, out_dst, in_ptr, in_src, u, v, num_samples: torch.empty_like(u, dtype=torch.bool))
+
+
 # ------------------------------------------------------------------------------------- projections
 def _proj_fwd(x, w, out_c: int, n_score: int, res_c: int, x_mask, x_scale: float):
     hs, score, res = _lib.proj_fwd(x, w, out_c, n_score, res_c, x_mask=x_mask, x_scale=x_scale)

@@ -97,6 +97,28 @@ class NormLayer(nn.Module):
         return self.norm(x)
 
 
+# Mirror of the `random` module's generator kept between calls of sample_range: the state tuple the last call
+# left behind and a numpy bit generator standing at exactly that state (when nothing else drew from `random`
+# in between, the next call starts from it without converting the 624 state words twice).
+_mt_mirror = {"state": None, "bg": None}
+_first_seen = {"buf": np.empty(0, dtype=np.int32)}
+
+
+def _first_occurrences(vals: np.ndarray, n: int) -> np.ndarray:
+    """Positions (ascending) of the first occurrence of every distinct value of ``vals`` (values in [0, n))."""
+    m = vals.size
+    if n > (1 << 26):  # no 256 MB scratch array for a sparse sample: sort instead
+        _, first = np.unique(vals, return_index=True)
+        first.sort()
+        return first
+    buf = _first_seen["buf"]
+    if buf.size < n:
+        buf = _first_seen["buf"] = np.empty(n, dtype=np.int32)
+    idx = np.arange(m, dtype=np.int32)
+    buf[vals[::-1]] = idx[::-1]          # of equal values the earliest position is written last and stays
+    return np.nonzero(buf[vals] == idx)[0]
+
+
 def sample_range(n: int, k: int) -> np.ndarray:
     """``random.sample(range(n), k)`` (``model/autoencoder.py:253`` draws the positive edges of the
     reconstruction loss that way) as an int64 array: the same k numbers in the same order, and the
@@ -114,10 +136,15 @@ def sample_range(n: int, k: int) -> np.ndarray:
     if not (0 < k <= n) or n <= setsize or n.bit_length() > 32:
         return np.asarray(random.sample(range(n), k), dtype=np.int64)
     inst = random._inst
-    version, st, gauss = inst.getstate()
-    start = {"bit_generator": "MT19937", "state": {"key": np.array(st[:-1], dtype=np.uint32), "pos": st[-1]}}
-    bg = np.random.MT19937()
-    bg.state = start
+    state = inst.getstate()
+    version, st, gauss = state
+    if _mt_mirror["bg"] is not None and _mt_mirror["state"] == state:
+        bg = _mt_mirror["bg"]
+        start = bg.state
+    else:
+        start = {"bit_generator": "MT19937", "state": {"key": np.array(st[:-1], dtype=np.uint32), "pos": st[-1]}}
+        bg = np.random.MT19937()
+        bg.state = start
     shift = np.uint64(32 - n.bit_length())
     chunk = int(k * (1 << n.bit_length()) / n * 1.05) + 64
     raws = np.empty(0, dtype=np.uint64)
@@ -126,9 +153,8 @@ def sample_range(n: int, k: int) -> np.ndarray:
         cand = (raws >> shift).astype(np.int64)
         pos = np.nonzero(cand < n)[0]
         vals = cand[pos]
-        _, first = np.unique(vals, return_index=True)   # first occurrence of every value
+        first = _first_occurrences(vals, n)   # a repeated value is a redraw for CPython too
         if first.size >= k:
-            first.sort()
             sel = first[:k]
             result = vals[sel]
             consumed = int(pos[sel[-1]]) + 1
@@ -137,5 +163,7 @@ def sample_range(n: int, k: int) -> np.ndarray:
     bg.state = start
     bg.random_raw(consumed)
     end = bg.state["state"]
-    inst.setstate((version, tuple(end["key"].tolist()) + (int(end["pos"]),), gauss))
+    state = (version, tuple(end["key"].tolist()) + (int(end["pos"]),), gauss)
+    inst.setstate(state)
+    _mt_mirror["state"], _mt_mirror["bg"] = state, bg
     return result

@@ -415,7 +415,7 @@ def test_custom_ops_are_registered_with_schemas_and_fake_kernels():
     import magic_amd  # noqa: F401
     from torch._subclasses.fake_tensor import FakeTensorMode
     names = ["csr_build", "proj_fwd", "proj_bwd_input", "proj_bwd_input_", "proj_bwd_weight", "gat_fwd_", "gat_bwd_",
-             "sce_fwd_bwd", "sce_loss", "linear_nobias", "knn_topk", "knn_merge", "readout"]
+             "sce_fwd_bwd", "sce_loss", "linear_nobias", "knn_topk", "knn_merge", "readout", "negative_filter"]
     for n in names:
         op = getattr(torch.ops.magic, n)
         assert "magic::" + n in str(op.default._schema)
@@ -447,6 +447,10 @@ def test_custom_ops_are_registered_with_schemas_and_fake_kernels():
         assert hs.shape == (n, 64) and score.shape == (n, 8) and res.shape == (n, 64)
         loss, d_x, d_t = torch.ops.magic.sce_fwd_bwd(f(n, 8), 5, f(1, 5), True, torch.empty(50, dtype=torch.int64, device=dev), 3.0)
         assert loss.shape == (1,) and d_x.shape == (n, 8) and d_t.shape == (5,)
+        i64 = dict(dtype=torch.int64, device=dev)
+        ok = torch.ops.magic.negative_filter(plan[0], torch.empty(e, **i32), plan[0], torch.empty(e, **i32),
+                                             torch.empty(125, **i64), torch.empty(125, **i64), 100)
+        assert ok.shape == (125,) and ok.dtype == torch.bool
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.magic.knn_topk(torch.zeros(10, 4), torch.zeros(2, 4), 1, 0)
 

@@ -109,6 +109,59 @@ def test_batch_by_the_library_equals_the_tensor_path(cuda, monkeypatch):
                 assert ta.dtype == tb.dtype and torch.equal(ta, tb), (which, name)
 
 
+def test_negative_pair_filter_equals_the_tensor_path(cuda):
+    """magic_negative_filter (segment scans + LDS table, one launch) against the same acceptance rule written
+    with tensor operations (sorted edge keys, search, stable sort of the candidates), bit for bit: candidates
+    that are edges (of hubs in both directions too), self-loops, repeats of accepted and of rejected pairs, a
+    quota smaller and larger than the number of passing pairs, an edgeless graph, and a python-loop check of
+    the rule itself on the small case."""
+    from magic_amd import _lib
+    from magic_amd.graph import Graph
+    from magic_amd.model.autoencoder import _accept_negatives, _negative_candidates, negative_candidate_count
+
+    gen = torch.Generator().manual_seed(11)
+    for n, e, hub_in, hub_out, m, quota in [(60, 300, 40, 30, 500, 100), (5000, 60000, 3000, 2500, 12500, 10000),
+                                            (5000, 60000, 3000, 2500, 16384, 20000), (300, 0, 0, 0, 375, 300),
+                                            (1, 0, 0, 0, 2, 1)]:
+        if e:
+            src, dst, _, _ = small_graph(n, e, 4, 4, seed=n + e, hub_deg=hub_in, hub_out=hub_out)
+            src, dst = torch.from_numpy(src), torch.from_numpy(dst)
+        else:
+            src = dst = torch.zeros(0, dtype=torch.int64)
+        g = Graph(src, dst, n).to(cuda)
+        s = g.structure.ensure_csr()
+        u = torch.randint(0, n, (m,), generator=gen)
+        v = torch.randint(0, n, (m,), generator=gen)
+        if e:
+            take = torch.randint(0, e, (m // 5,), generator=gen)   # a fifth of the candidates are edges,
+            u[:m // 5], v[:m // 5] = src[take], dst[take]
+            mix = torch.randperm(m, generator=gen)                  # spread over the draw order
+            u, v = u[mix], v[mix]
+        u[3 % m] = v[3 % m]                                         # a self-loop
+        if m > 20:
+            u[m - 5:], v[m - 5:] = u[5:10].clone(), v[5:10].clone()  # repeats of earlier candidates
+        u, v = u.to(cuda), v.to(cuda)
+        got = _lib.negative_filter(s.out_ptr, s.out_dst, s.in_ptr, s.in_src, u, v, quota)
+        want = _accept_negatives(g, u, v, quota)
+        assert got.dtype == torch.bool and torch.equal(got, want), (n, e, m)
+        assert int(got.sum()) <= quota
+        if n == 60:
+            edges = set(zip(src.tolist(), dst.tolist()))
+            seen, acc, ref = set(), 0, []
+            for a, b in zip(u.tolist(), v.tolist()):
+                good = a != b and (a, b) not in edges and (a, b) not in seen and acc < quota
+                seen.add((a, b))
+                acc += good
+                ref.append(good)
+            assert got.tolist() == ref
+    # the model's own draw goes through the library on the GPU
+    nu, nv, ok = _negative_candidates(g, 1)
+    assert nu.numel() == negative_candidate_count(1) and ok.dtype == torch.bool and not bool(ok.any())  # one node
+    with pytest.raises(_lib.MagicHipError):
+        big = torch.zeros(_lib.NEGATIVE_FILTER_MAX + 1, dtype=torch.int64, device=cuda)
+        _lib.negative_filter(s.out_ptr, s.out_dst, s.in_ptr, s.in_src, big, big, 1)
+
+
 @pytest.mark.parametrize("nt,nq,d,k", [(5000, 777, 64, 10), (300, 130, 64, 10), (20000, 300, 64, 200),
                                         (400, 200, 256, 8), (100, 50, 2048, 2), (3000, 257, 32, 5)])
 def test_knn_matches_exact_oracle(cuda, nt, nq, d, k):
