@@ -359,8 +359,8 @@ int magic_walk_order(int32_t n_arrays, const int32_t *const *ptr, const int32_t 
  * accept[i] = 1 for the first `num_samples` that are no edge, no self-loop and no repeat of an
  * earlier candidate, 0 for all others (also for ids outside [0, n_nodes)).  The graph comes as
  * both segment arrays (out_ptr/out_dst by source, in_ptr/in_src by destination, as
- * magic_csr_build writes them); the shorter segment of a pair is scanned.  Integer work, one
- * launch, nothing read back.  n_candidates <= MAGIC_NEGATIVE_FILTER_MAX.
+ * magic_csr_build writes them); the shorter segment of a pair is scanned.  Integer work, two
+ * launches, nothing read back.  n_candidates <= MAGIC_NEGATIVE_FILTER_MAX.
  * ---------------------------------------------------------------------------------- */
 #define MAGIC_NEGATIVE_FILTER_MAX 16384
 int magic_negative_filter(int64_t n_nodes, const int32_t *out_ptr, const int32_t *out_dst,

@@ -2,12 +2,14 @@
 // model/autoencoder.py:251 of the reference): of m candidate (src, dst) pairs, in draw order, the first
 // `num_samples` that are no edge of the graph, no self-loop and no repeat of an earlier candidate.
 //
-// One workgroup does the whole job (m is at most a few thousand more than the 10,000 pairs the loss uses):
-//   edge test    the shorter of the source's out-segment and the destination's in-segment is scanned;
-//   repeats      an open-addressing table in LDS keyed by src * N + dst keeps, per key, the smallest candidate
-//                index (compare-and-swap for the empty slot, atomic minimum afterwards): whoever is not the
-//                index stored for its key is a repeat.  The result does not depend on the insertion order;
-//   the count    ballot / population count per wavefront, wavefront totals through LDS, 1024 candidates a round.
+// Two launches:
+//   edge test    one thread per candidate over the whole chip: the shorter of the source's out-segment and the
+//                destination's in-segment is scanned (one workgroup doing this for every candidate spends its time
+//                waiting on dependent loads: 250 us against 10);
+//   repeats and  one workgroup: an open-addressing table in LDS keyed by src * N + dst keeps, per key, the smallest
+//   the count    candidate index (compare-and-swap for the empty slot, atomic minimum afterwards): whoever is not the
+//                index stored for its key is a repeat -- the result does not depend on the insertion order; then
+//                ballot / population count per wavefront, wavefront totals through LDS, 1024 candidates a round.
 #include "common.h"
 
 namespace {
@@ -31,40 +33,13 @@ __device__ __forceinline__ int neg_hash(int64_t key) {
     return (int)(((uint64_t)key * 0x9E3779B97F4A7C15ull) >> 40) & (NEG_SLOTS - 1);
 }
 
-__global__ __launch_bounds__(NEG_THREADS) void k_negative_filter(NegArgs a) {
-    extern __shared__ int slots[];
-    __shared__ int wave_cnt[NEG_THREADS / 64];
-    __shared__ int accepted;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < NEG_SLOTS; i += NEG_THREADS) slots[i] = -1;
-    if (tid == 0) accepted = 0;
-    __syncthreads();
-    volatile int *vslots = slots;
-    unsigned good = 0;  // bit j: candidate j * 1024 + tid passed the edge / self-loop test
-    int where[NEG_PER];
-#pragma unroll
-    for (int j = 0; j < NEG_PER; ++j) {
-        const int i = j * NEG_THREADS + tid;
-        where[j] = 0;
-        if (i >= a.m) continue;
-        const int64_t u = a.u[i], v = a.v[i];
-        if (u < 0 || u >= a.n || v < 0 || v >= a.n) continue;  // no node pair at all
-        const int64_t key = u * a.n + v;
-        int h = neg_hash(key);
-        while (true) {
-            int cur = vslots[h];
-            if (cur < 0) {
-                cur = atomicCAS(&slots[h], -1, i);
-                if (cur < 0) break;  // claimed the empty slot
-            }
-            if (a.u[cur] * a.n + a.v[cur] == key) {  // a slot never changes its key, only to a smaller index
-                atomicMin(&slots[h], i);
-                break;
-            }
-            h = (h + 1) & (NEG_SLOTS - 1);
-        }
-        where[j] = h;
-        if (u == v) continue;
+// pass[i] = 1 when candidate i names two different nodes of the graph that no edge joins
+__global__ __launch_bounds__(256) void k_negative_edges(NegArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.m) return;
+    const int64_t u = a.u[i], v = a.v[i];
+    bool pass = false;
+    if (u >= 0 && u < a.n && v >= 0 && v < a.n && u != v) {
         const int ob = a.out_ptr[u], oe = a.out_ptr[u + 1], ib = a.in_ptr[v], ie = a.in_ptr[v + 1];
         bool is_edge = false;
         if (oe - ob <= ie - ib) {
@@ -72,13 +47,57 @@ __global__ __launch_bounds__(NEG_THREADS) void k_negative_filter(NegArgs a) {
         } else {
             for (int e = ib; e < ie; ++e) is_edge |= a.in_src[e] == (int32_t)u;
         }
-        if (!is_edge) good |= 1u << j;
+        pass = !is_edge;
+    }
+    a.ok[i] = pass ? 1 : 0;
+}
+
+// in: ok[i] = the edge test's verdict; out: ok[i] = accepted
+__global__ __launch_bounds__(NEG_THREADS) void k_negative_filter(NegArgs a) {
+    extern __shared__ int slots[];
+    __shared__ int wave_cnt[NEG_THREADS / 64];
+    __shared__ int accepted;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this thread's candidates (all loads in flight together)
+    int64_t key[NEG_PER];
+    unsigned good = 0;
+#pragma unroll
+    for (int j = 0; j < NEG_PER; ++j) {
+        const int i = min(j * NEG_THREADS + tid, a.m - 1);
+        const int64_t u = a.u[i], v = a.v[i];
+        key[j] = (u >= 0 && u < a.n && v >= 0 && v < a.n && j * NEG_THREADS + tid < a.m) ? u * a.n + v : -1;
+        if (a.ok[i]) good |= 1u << j;
+    }
+    for (int i = tid; i < NEG_SLOTS; i += NEG_THREADS) slots[i] = -1;
+    if (tid == 0) accepted = 0;
+    __syncthreads();
+    volatile int *vslots = slots;
+    int where[NEG_PER];
+#pragma unroll
+    for (int j = 0; j < NEG_PER; ++j) {
+        const int i = j * NEG_THREADS + tid;
+        where[j] = 0;
+        if (key[j] < 0) continue;  // no node pair at all
+        int h = neg_hash(key[j]);
+        while (true) {
+            int cur = vslots[h];
+            if (cur < 0) {
+                cur = atomicCAS(&slots[h], -1, i);
+                if (cur < 0) break;  // claimed the empty slot
+            }
+            if (a.u[cur] * a.n + a.v[cur] == key[j]) {  // a slot never changes its key, only to a smaller index
+                atomicMin(&slots[h], i);
+                break;
+            }
+            h = (h + 1) & (NEG_SLOTS - 1);
+        }
+        where[j] = h;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NEG_PER; ++j) {
         const int i = j * NEG_THREADS + tid;
-        const bool ok = ((good >> j) & 1u) && slots[where[j]] == i;
+        const bool ok = ((good >> j) & 1u) && key[j] >= 0 && slots[where[j]] == i;
         const unsigned long long b = __ballot(ok);
         if (lane == 0) wave_cnt[wave] = __popcll(b);
         __syncthreads();
@@ -122,6 +141,7 @@ extern "C" int magic_negative_filter(int64_t n_nodes, const int32_t *out_ptr, co
     a.u = cand_src, a.v = cand_dst;
     a.num_samples = num_samples;
     a.ok = accept;
+    MAGIC_LAUNCH("negative_edges", k_negative_edges, (n_candidates + 255) / 256, 256, 0, stream, a);
     MAGIC_LAUNCH("negative_filter", k_negative_filter, 1, NEG_THREADS, lds, stream, a);
     return magic::launch_status();
 }

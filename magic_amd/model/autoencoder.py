@@ -79,7 +79,7 @@ def _negative_candidates(g: Graph, num_samples: int, generator: torch.Generator 
     (``model/autoencoder.py:251``) with fixed shapes, so that nothing is read back to the host:
     ``negative_candidate_count(num_samples)`` uniformly drawn pairs and a mask that accepts, in draw
     order, the first ``num_samples`` of them that are no edge of ``g``, no self-loop and no repeat of an
-    earlier accepted pair (DGL samples without replacement).  On the GPU the mask is one launch of the
+    earlier accepted pair (DGL samples without replacement).  On the GPU the mask is one call of the
     library (``magic_negative_filter``: segment scans and an LDS table instead of an edge-key sort, a
     search and a sort of the candidates)."""
     n = g.num_nodes()

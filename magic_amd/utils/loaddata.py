@@ -72,7 +72,7 @@ def _edge_one_hot(g: Graph, edge_feature_dim: int) -> torch.Tensor:
             return attr
         _edge_attr_bytes -= attr.numel() * 4
         del g._cache["edge_onehot"]
-    attr = F.one_hot(t.view(-1).long(), num_classes=edge_feature_dim).float()
+    attr = _one_hot_float(t, edge_feature_dim)
     nbytes = attr.numel() * 4
     if t.is_cuda and _edge_attr_bytes + nbytes <= _EDGE_ATTR_CACHE_BYTES:
         g._cache["edge_onehot"] = (weakref.ref(t), t._version, edge_feature_dim, attr, attr._version)
@@ -80,11 +80,21 @@ def _edge_one_hot(g: Graph, edge_feature_dim: int) -> torch.Tensor:
     return attr
 
 
+def _one_hot_float(ids: torch.Tensor, num_classes: int) -> torch.Tensor:
+    """``F.one_hot(ids, num_classes).float()``; on the GPU written directly as float32 (two launches instead of
+    the int64 one-hot, its fill and a conversion)."""
+    ids = ids.view(-1).long()
+    if not ids.is_cuda:
+        return F.one_hot(ids, num_classes=num_classes).float()
+    out = torch.zeros(ids.numel(), num_classes, dtype=torch.float32, device=ids.device)
+    return out.scatter_(1, ids.view(-1, 1), 1.0)
+
+
 def transform_graph(g: Graph, node_feature_dim: int, edge_feature_dim: int) -> Graph:
     """``utils/loaddata.py:257-260``: one-hot float attributes on a clone (the node attributes fresh on every
     call: the masking step writes into them)."""
     new_g = g.clone()
-    new_g.ndata["attr"] = F.one_hot(g.ndata["type"].view(-1).long(), num_classes=node_feature_dim).float()
+    new_g.ndata["attr"] = _one_hot_float(g.ndata["type"], node_feature_dim)
     new_g.edata["attr"] = _edge_one_hot(g, edge_feature_dim)
     new_g.mark_edge_attr_onehot()
     return new_g
