@@ -192,17 +192,23 @@ def csr_build(src: torch.Tensor, dst: torch.Tensor, num_nodes: int):
 
 
 # ------------------------------------------------------------------------------------- union graphs
-def concat_offset(jobs: torch.Tensor, elem_bytes: int, device) -> None:
-    """``jobs``: CPU int64 tensor [n, 4] of (source address or 0, destination address, length, addend);
-    runs destination[i] = source[i] + addend for every job (one launch for all of them)."""
+def concat_offset(groups, device) -> None:
+    """``groups``: [(jobs, elem_bytes), ...] with ``jobs`` a list of (source address or 0, destination address,
+    length, addend); runs destination[i] = source[i] + addend for every job, one launch per group.  The job
+    tables of all groups travel to the device in one copy."""
     lib = load()
-    n = int(jobs.shape[0])
-    if n == 0:
+    groups = [(jobs, int(width)) for jobs, width in groups if len(jobs)]
+    if not groups:
         return
+    flat = [row for jobs, _ in groups for row in jobs]
     # pinned + asynchronous: a pageable copy would make the host wait for everything queued so far
-    table = jobs.contiguous().pin_memory().to(device, non_blocking=True)
-    _check(lib.magic_concat_offset(int(elem_bytes), n, table.data_ptr(), int(jobs[:, 2].max()), _stream()),
-           "magic_concat_offset")
+    table = torch.tensor(flat, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
+    base, stream = table.data_ptr(), _stream()
+    first = 0
+    for jobs, width in groups:
+        _check(lib.magic_concat_offset(width, len(jobs), base + 32 * first, max(row[2] for row in jobs), stream),
+               "magic_concat_offset")
+        first += len(jobs)
 
 
 def walk_order(ptrs, light_max: int):

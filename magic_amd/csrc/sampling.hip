@@ -29,9 +29,7 @@ struct NegArgs {
     uint8_t *ok;
 };
 
-__device__ __forceinline__ int neg_hash(int64_t key) {
-    return (int)(((uint64_t)key * 0x9E3779B97F4A7C15ull) >> 40) & (NEG_SLOTS - 1);
-}
+static_assert(NEG_MAX <= 65536, "a candidate index must fit the low half of a table slot");
 
 // pass[i] = 1 when candidate i names two different nodes of the graph that no edge joins
 __global__ __launch_bounds__(256) void k_negative_edges(NegArgs a) {
@@ -68,6 +66,8 @@ __global__ __launch_bounds__(NEG_THREADS) void k_negative_filter(NegArgs a) {
         key[j] = (u >= 0 && u < a.n && v >= 0 && v < a.n && j * NEG_THREADS + tid < a.m) ? u * a.n + v : -1;
         if (a.ok[i]) good |= 1u << j;
     }
+    // a slot holds (15-bit tag of the key) << 16 | candidate index: a probe that meets another key sees another tag
+    // (all but one time in 32,768) and moves on without fetching that candidate's pair from memory
     for (int i = tid; i < NEG_SLOTS; i += NEG_THREADS) slots[i] = -1;
     if (tid == 0) accepted = 0;
     __syncthreads();
@@ -78,16 +78,22 @@ __global__ __launch_bounds__(NEG_THREADS) void k_negative_filter(NegArgs a) {
         const int i = j * NEG_THREADS + tid;
         where[j] = 0;
         if (key[j] < 0) continue;  // no node pair at all
-        int h = neg_hash(key[j]);
+        const uint64_t mix = (uint64_t)key[j] * 0x9E3779B97F4A7C15ull;
+        int h = (int)(mix >> 40) & (NEG_SLOTS - 1);
+        const int tag = (int)((mix >> 20) & 0x7fffu);  // 15 bits: a packed slot stays non-negative
+        const int mine = (tag << 16) | i;
         while (true) {
             int cur = vslots[h];
             if (cur < 0) {
-                cur = atomicCAS(&slots[h], -1, i);
+                cur = atomicCAS(&slots[h], -1, mine);
                 if (cur < 0) break;  // claimed the empty slot
             }
-            if (a.u[cur] * a.n + a.v[cur] == key[j]) {  // a slot never changes its key, only to a smaller index
-                atomicMin(&slots[h], i);
-                break;
+            if ((cur >> 16) == tag) {
+                const int c = cur & 0xffff;
+                if (a.u[c] * a.n + a.v[c] == key[j]) {  // a slot never changes its key, only to a smaller index
+                    atomicMin(&slots[h], mine);
+                    break;
+                }
             }
             h = (h + 1) & (NEG_SLOTS - 1);
         }
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(NEG_THREADS) void k_negative_filter(NegArgs a) {
 #pragma unroll
     for (int j = 0; j < NEG_PER; ++j) {
         const int i = j * NEG_THREADS + tid;
-        const bool ok = ((good >> j) & 1u) && key[j] >= 0 && slots[where[j]] == i;
+        const bool ok = ((good >> j) & 1u) && key[j] >= 0 && (slots[where[j]] & 0xffff) == i;
         const unsigned long long b = __ballot(ok);
         if (lane == 0) wave_cnt[wave] = __popcll(b);
         __syncthreads();

@@ -450,14 +450,18 @@ def _union_structure_device(graphs, n_off, e_off):
 
     def ok(t, dt):
         return t.dtype == dt and t.is_contiguous() and t.is_cuda
-    for x in ss:
-        if not (ok(x.src, i64) and ok(x.dst, i64) and ok(x.in_ptr, i32) and ok(x.out_ptr, i32)):
-            return None
-        if not all(ok(getattr(x, a), i32) for a in _STRUCT_I32):
-            return None
-        for pl in (x.plan_in, x.plan_out):
-            if not all(ok(getattr(pl, a), i32) for a in _PLAN_I32):
-                return None
+
+    def qualifies(x):
+        # (asked once per component: the arrays of a structure are set once and never rebound)
+        key = (id(x.in_ptr), id(x.plan_in), id(x.plan_out))
+        if getattr(x, "_union_ok", (None, False))[0] != key:
+            good = ok(x.src, i64) and ok(x.dst, i64) and ok(x.in_ptr, i32) and ok(x.out_ptr, i32) and \
+                all(ok(getattr(x, a), i32) for a in _STRUCT_I32) and \
+                all(ok(getattr(pl, a), i32) for pl in (x.plan_in, x.plan_out) for a in _PLAN_I32)
+            x._union_ok = (key, good)
+        return x._union_ok[1]
+    if not all(qualifies(x) for x in ss):
+        return None
     dev = ss[0].src.device
     N, E = n_off[-1], e_off[-1]
     jobs32, jobs64 = [], []
@@ -502,8 +506,7 @@ def _union_structure_device(graphs, n_off, e_off):
         add_jobs(jobs32, chunk_beg, [pl.chunk_beg for pl in pls], c_off, e_off, 4)
         add_jobs(jobs32, chunk_end, [pl.chunk_end for pl in pls], c_off, e_off, 4)
         plans[name] = (heavy_node, heavy_cptr, chunk_node, chunk_beg, chunk_end)
-    _lib.concat_offset(torch.tensor(jobs64, dtype=i64).view(-1, 4), 8, dev)
-    _lib.concat_offset(torch.tensor(jobs32, dtype=i64).view(-1, 4), 4, dev)
+    _lib.concat_offset([(jobs64, 8), (jobs32, 4)], dev)   # one table upload, one launch per element width
     (o_in, x_in), (o_out, x_out) = _lib.walk_order([s.in_ptr, s.out_ptr], LIGHT_MAX)
     s.plan_in = SegmentPlan(s.in_ptr, *plans["plan_in"], order=o_in, xcd_start=x_in)
     s.plan_out = SegmentPlan(s.out_ptr, *plans["plan_out"], order=o_out, xcd_start=x_out)
