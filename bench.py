@@ -277,7 +277,7 @@ def gat_leg(args, workload, steps, warmup, world, rank, dev):
     from magic_amd.model.autoencoder import GMAEModel, _negative_candidates
     from magic_amd.model.step import CapturedTrainStep, make_adam
     from magic_amd.parallel import FlatGradAllReduce, broadcast_parameters
-    from magic_amd.utils.utils import set_random_seed
+    from magic_amd.utils.utils import create_optimizer, set_random_seed
 
     batch_graphs = 1
     shape_name = workload
@@ -321,7 +321,7 @@ def gat_leg(args, workload, steps, warmup, world, rank, dev):
             # (mask permutation drawn on the device, as model/autoencoder.py:201 does for a model on the GPU)
             e2e_model = GMAEModel(n_dim, e_dim, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5,
                                   "sce", 3, mask_rng="device").to(dev)
-            e2e_opt = torch.optim.Adam(e2e_model.parameters(), lr=1e-3, weight_decay=5e-4, fused=True)
+            e2e_opt = create_optimizer("adam", e2e_model, 1e-3, 5e-4)   # train.py:82 with utils/config.py defaults
             pool = [(p_, 0) for p_ in parts]
             loader = [list(range(batch_graphs))]
             batch_level_train(e2e_model, pool, loader * 4, e2e_opt, 1, dev, n_dim, e_dim, progress=False)

@@ -369,6 +369,27 @@ int magic_negative_filter(int64_t n_nodes, const int32_t *out_ptr, const int32_t
                           uint8_t *accept /* [n_candidates] */, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Optimizer step: torch.optim.Adam as the reference builds it (utils/utils.py:24-31,
+ * lr / weight_decay from utils/config.py:20-28; weight decay is the L2 term added to the
+ * gradient, no amsgrad) over all parameter tensors at once:
+ *   t = *step_device + 1;  g = grad + weight_decay * param;
+ *   exp_avg += (1 - beta1) (g - exp_avg);  exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) g^2;
+ *   param -= lr / (1 - beta1^t) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^t) + eps)
+ * and *step_device = t afterwards (int64 in device memory: a step recorded into a HIP graph
+ * counts on its own).  `slots` is a HOST array of n_tensors entries (contiguous float32 device
+ * tensors); the pointers are passed to the kernels by value, 64 tensors per launch.
+ * ---------------------------------------------------------------------------------- */
+typedef struct magic_adam_slot {
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t n;
+} magic_adam_slot;
+int magic_adam_step(int32_t n_tensors, const magic_adam_slot *slots, int64_t *step_device, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Brute-force k nearest neighbours (Euclidean), replacing
  * sklearn.neighbors.NearestNeighbors(...).kneighbors at model/eval.py:154,158 and
  * :306,311.  Squared distances |q|^2 - 2 q.t + |t|^2 are formed in float64 on the f64

@@ -40,6 +40,7 @@ SYMBOLS = {
     "magic_walk_order": (c_i32, [c_i32, C.POINTER(c_vp), C.POINTER(c_i32), c_i32, C.POINTER(c_vp), C.POINTER(c_vp),
                                  c_vp, c_sz, c_vp]),
     "magic_negative_filter": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "magic_adam_step": (c_i32, [c_i32, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "magic_proj_fwd": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_i64,
                                c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "magic_proj_fwd_workspace_bytes": (c_sz, [c_i32, c_i32]),
@@ -227,6 +228,23 @@ def walk_order(ptrs, light_max: int):
     _check(lib.magic_walk_order(k, arr_p, arr_n, int(light_max), arr_o, arr_x, ws.data_ptr(), ws.numel(), _stream()),
            "magic_walk_order")
     return outs
+
+
+class MagicAdamSlot(C.Structure):
+    """``magic_adam_slot`` of include/magic_hip.h."""
+    _fields_ = [("param", c_vp), ("grad", c_vp), ("exp_avg", c_vp), ("exp_avg_sq", c_vp), ("n", c_i64)]
+
+
+def adam_step(rows, step: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float):
+    """One Adam step over ``rows`` = [(param, grad, exp_avg, exp_avg_sq), ...] (contiguous float32 CUDA
+    tensors); ``step`` is the int64 device counter the call advances."""
+    n = len(rows)
+    slots = (MagicAdamSlot * max(n, 1))()
+    for i, (p, g, m, v) in enumerate(rows):
+        sl = slots[i]
+        sl.param, sl.grad, sl.exp_avg, sl.exp_avg_sq, sl.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+    _check(load().magic_adam_step(n, C.cast(slots, c_vp), _dev(step, torch.int64, "step"), lr, beta1, beta2, eps,
+                                  weight_decay, _stream()), "magic_adam_step")
 
 
 NEGATIVE_FILTER_MAX = 16384  # MAGIC_NEGATIVE_FILTER_MAX

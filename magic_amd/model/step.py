@@ -24,8 +24,10 @@ from ..utils.utils import sample_range
 
 def make_adam(model, lr: float, weight_decay: float, capturable: bool = True):
     """Adam as the reference configures it (``utils/utils.py:24-31``: L2 term added to the gradient),
-    as one multi-tensor launch; ``capturable`` keeps its step counter on the device."""
-    return torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=True, capturable=capturable)
+    as one multi-tensor launch of the library with its step counter on the device (so every instance can be
+    recorded into a HIP graph; ``capturable`` is kept for callers written against torch's fused Adam)."""
+    from ..optim import FusedAdam
+    return FusedAdam(model.parameters(), lr=lr, weight_decay=weight_decay)
 
 
 def _shared_pool(model):

@@ -19,8 +19,11 @@ def create_optimizer(opt, model, lr, weight_decay):
         # (same update rule; the model lives on the GPU by the time the reference builds its
         # optimizer: train.py:99-101)
         params = list(parameters)
-        on_gpu = len(params) > 0 and all(p.device.type == "cuda" for p in params)
-        return optim.Adam(params, fused=on_gpu, **opt_args)
+        on_gpu = len(params) > 0 and all(p.device.type == "cuda" and p.dtype == torch.float32 for p in params)
+        if on_gpu:
+            from ..optim import FusedAdam
+            return FusedAdam(params, **opt_args)
+        return optim.Adam(params, **opt_args)
     if opt_lower == "adamw":
         return optim.AdamW(parameters, **opt_args)
     if opt_lower == "adadelta":

@@ -183,3 +183,50 @@ def test_entity_level_loop_with_recorded_steps_trains(cuda):
                        progress=False, capture=True)
     assert not torch.equal(w0, mine.encoder.gats[0].fc.weight)
     assert all(bool(torch.isfinite(p).all()) for p in mine.parameters())
+
+
+def test_fused_adam_equals_torch_adam(cuda):
+    """magic_adam_step (one multi-tensor launch, step count on the device) against torch.optim.Adam in float64
+    on the same gradients: 70 tensors (more than one launch holds) of ragged sizes from 1 element to several
+    2048-element chunks, weight decay on, six steps; then the state the optimizer keeps and a second parameter
+    group with its own hyper-parameters."""
+    from magic_amd.optim import FusedAdam
+    from magic_amd.utils.utils import create_optimizer
+    gen = torch.Generator().manual_seed(5)
+    sizes = [(1,), (7,), (2048,), (2049,), (64, 33), (300, 41), (5000,)] * 10
+    base = [torch.randn(*s, generator=gen) for s in sizes]
+    mine = [torch.nn.Parameter(b.clone().to(cuda)) for b in base]
+    ref = [torch.nn.Parameter(b.clone().double()) for b in base]
+    om = FusedAdam([dict(params=mine[:60]), dict(params=mine[60:], lr=3e-3, weight_decay=0.0, betas=(0.8, 0.99))],
+                   lr=1e-3, weight_decay=5e-4)
+    orf = torch.optim.Adam([dict(params=ref[:60]), dict(params=ref[60:], lr=3e-3, weight_decay=0.0, betas=(0.8, 0.99))],
+                           lr=1e-3, weight_decay=5e-4)
+    for step in range(6):
+        for i, (pm, pr) in enumerate(zip(mine, ref)):
+            if step == 2 and i == 5:
+                pm.grad = pr.grad = None      # a parameter without a gradient is left alone for that step
+                continue
+            g = torch.randn(pm.shape, generator=gen) * (10.0 ** (i % 5 - 2))
+            pm.grad, pr.grad = g.to(cuda), g.double()
+        om.step()
+        orf.step()
+    for i, (pm, pr) in enumerate(zip(mine, ref)):
+        if i == 5:
+            continue   # (skipped one step: torch counts steps per parameter, the fused kernel per group)
+        err = (pm.detach().cpu().double() - pr.detach()).abs().max() / pr.detach().abs().max().clamp_min(1e-3)
+        assert float(err) < 2e-6, (i, float(err))
+    st = om.state[mine[0]]
+    assert int(st["step"]) == 6 and st["exp_avg"].shape == mine[0].shape and st["exp_avg_sq"].dtype == torch.float32
+    assert om.state[mine[0]]["step"] is om.state[mine[1]]["step"] and om.state[mine[65]]["step"] is not st["step"]
+    sd = om.state_dict()
+    om2 = FusedAdam([dict(params=mine[:60]), dict(params=mine[60:])], lr=1e-3)
+    om2.load_state_dict(sd)
+    assert om2.param_groups[1]["lr"] == 3e-3 and int(om2.state[mine[3]]["step"]) == 6
+    # the reference's factory hands out this optimizer for a model on the GPU and torch's own on the CPU
+    lin = torch.nn.Linear(4, 3)
+    assert type(create_optimizer("adam", lin, 1e-3, 5e-4)) is torch.optim.Adam
+    assert isinstance(create_optimizer("adam", lin.to(cuda), 1e-3, 5e-4), FusedAdam)
+    cpu_p = torch.nn.Parameter(torch.zeros(3))
+    cpu_p.grad = torch.ones(3)
+    with pytest.raises(Exception, match="GPU"):
+        FusedAdam([cpu_p], lr=1e-3).step()

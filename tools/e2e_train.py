@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from magic_amd import synth  # noqa: E402
 from magic_amd.model.autoencoder import GMAEModel  # noqa: E402
 from magic_amd.model.train import batch_level_train  # noqa: E402
-from magic_amd.utils.utils import set_random_seed  # noqa: E402
+from magic_amd.utils.utils import create_optimizer, set_random_seed  # noqa: E402
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n_graphs = int(args[0]) if args else 48
@@ -24,7 +24,7 @@ dev = torch.device("cuda:0")
 n, e, n_dim, e_dim, hidden, layers = synth.SHAPES["streamspot"]
 set_random_seed(0)
 model = GMAEModel(n_dim, e_dim, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(dev)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4, fused=True)
+opt = create_optimizer("adam", model, 1e-3, 5e-4)
 graphs = []
 for i in range(n_graphs):
     g = synth.make_graph(n, e, n_dim, e_dim, seed=1002 + i, attrs=False).to(dev)

@@ -10,6 +10,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from magic_amd import synth  # noqa: E402
 from magic_amd.model.autoencoder import GMAEModel  # noqa: E402
+from magic_amd.utils.utils import create_optimizer  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "streamspot_real"
 if name == "e2e":
@@ -21,7 +22,7 @@ if name == "e2e":
     for p_ in parts:
         p_.structure.ensure_csr()
     model = GMAEModel(n_dim, e_dim, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4, fused=True)
+    opt = create_optimizer("adam", model, 1e-3, 5e-4)
     pool = [(p_, 0) for p_ in parts]
     loader = [list(range(12))]
     batch_level_train(model, pool, loader, opt, 3, dev, n_dim, e_dim, progress=False)
@@ -37,7 +38,7 @@ n, e, n_dim, e_dim, hidden, layers = synth.SHAPES[name]
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = GMAEModel(n_dim, e_dim, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(dev).train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4, fused=True)
+opt = create_optimizer("adam", model, 1e-3, 5e-4)
 g = synth.make_graph(n, e, n_dim, e_dim, seed=1, attrs=True).to(dev)
 g.structure.ensure_csr()
 g.edge_types_csc()
