@@ -148,6 +148,27 @@ class _PairLinearFn(torch.autograd.Function):
         return d_rows, None, d_w, d_b, None
 
 
+class _EdgeHeadLossFn(torch.autograd.Function):
+    """``BCELoss(Sigmoid(Linear(LeakyReLU(h_pre))), [1]*n_pos + [0]*n_neg)`` with the negative pairs weighted by
+    ``neg_valid`` -- the tail of the edge-reconstruction loss (``model/autoencoder.py:257-266`` through the head
+    of ``:114-119``) as two passes over ``h_pre`` (``magic_edge_head_fwd`` / ``_bwd``) instead of ~25 small
+    tensor operations."""
+
+    @staticmethod
+    def forward(ctx, h_pre, w2, b2, neg_valid, n_pos, slope):
+        loss, d_logit, wsum = torch.ops.magic.edge_head_fwd(h_pre, w2, b2, neg_valid, int(n_pos), float(slope))
+        ctx.save_for_backward(h_pre, w2, d_logit, wsum)
+        ctx.slope = float(slope)
+        ctx.w2_shape, ctx.b2_shape = w2.shape, b2.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        h_pre, w2, d_logit, wsum = ctx.saved_tensors
+        d_h, d_w2, d_b2 = torch.ops.magic.edge_head_bwd(h_pre, w2, d_logit, wsum, g.contiguous().float(), ctx.slope)
+        return d_h, d_w2.view(ctx.w2_shape), d_b2.view(ctx.b2_shape), None, None, None
+
+
 class GMAEModel(nn.Module):
     """``model/autoencoder.py:55-305``."""
 
@@ -273,6 +294,23 @@ class GMAEModel(nn.Module):
         return FusedCfg(g.structure.ensure_csr(), etype, g.edge_types_csr(), enc[0].edge_feat, len(enc), H, D, d.out_feat,
                         _pad_head_dim(d.out_feat), enc[0].leaky_relu.negative_slope, res_kinds, masks, scale)
 
+    def _edge_recon_loss(self, rows, n_pos, n_neg, neg_valid):
+        """The BCE of ``model/autoencoder.py:257-266`` on the library's loss tail, or None when the head is not
+        the one the reference builds (``:114-119``) or the operands are not float32 rows on the GPU."""
+        fc1, act, fc2, sig = self.edge_recon_fc
+        if not (rows.is_cuda and rows.dtype == torch.float32 and isinstance(act, nn.LeakyReLU)
+                and isinstance(sig, nn.Sigmoid) and isinstance(fc2, nn.Linear) and fc2.out_features == 1
+                and fc2.bias is not None and fc2.in_features % 4 == 0 and fc2.in_features <= 1024
+                and isinstance(self.recon_loss, nn.BCELoss) and self.recon_loss.weight is None
+                and self.recon_loss.reduction == "mean" and n_pos + n_neg > 0):
+            return None
+        if neg_valid is not None:
+            neg_valid = torch.as_tensor(neg_valid).to(rows.device)
+            if neg_valid.dtype not in (torch.bool, torch.uint8):
+                neg_valid = neg_valid != 0
+        h_pre = _PairLinearFn.apply(rows, n_pos + n_neg, fc1.weight, fc1.bias, True)
+        return _EdgeHeadLossFn.apply(h_pre, fc2.weight, fc2.bias, neg_valid, n_pos, act.negative_slope)
+
     def _edge_recon(self, rows, n_pairs, lib_gemm=False):
         """``edge_recon_fc`` (``model/autoencoder.py:75-78``) on the pairs (row i, row n_pairs + i) of
         ``rows``, with the weight gradients of its two linear layers on the streaming dW kernel (a
@@ -350,13 +388,16 @@ class GMAEModel(nn.Module):
             loss_sce = sce_loss_masked(recon_p, x_target, mask_nodes, self._alpha_l, n_dim=n_dim)
         loss = loss_sce
         # autoencoder.py:257-266: sampled edge reconstruction
-        y_pred = self._edge_recon(samples, n_pairs, lib_gemm=samples.is_cuda).squeeze(-1)
-        y = torch.cat([torch.ones(len(pos[0]), device=g.device), torch.zeros(len(neg[0]), device=g.device)])
-        if neg_valid is None:
-            loss_bce = self.recon_loss(y_pred, y)
-        else:
-            w = torch.cat([torch.ones(len(pos[0]), device=g.device), torch.as_tensor(neg_valid).to(g.device).float()])
-            loss_bce = nn.functional.binary_cross_entropy(y_pred, y, weight=w, reduction="sum") / w.sum()
+        loss_bce = self._edge_recon_loss(samples, len(pos[0]), len(neg[0]), neg_valid)
+        if loss_bce is None:
+            y_pred = self._edge_recon(samples, n_pairs, lib_gemm=samples.is_cuda).squeeze(-1)
+            y = torch.cat([torch.ones(len(pos[0]), device=g.device), torch.zeros(len(neg[0]), device=g.device)])
+            if neg_valid is None:
+                loss_bce = self.recon_loss(y_pred, y)
+            else:
+                w = torch.cat([torch.ones(len(pos[0]), device=g.device),
+                               torch.as_tensor(neg_valid).to(g.device).float()])
+                loss_bce = nn.functional.binary_cross_entropy(y_pred, y, weight=w, reduction="sum") / w.sum()
         loss = loss + loss_bce
         if return_parts:
             return loss, dict(sce=loss_sce, bce=loss_bce, recon=recon, hidden=all_hidden, mask_nodes=mask_nodes)

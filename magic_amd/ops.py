@@ -303,6 +303,20 @@ def _linear_backward(ctx, dy):
 torch.library.register_autograd("magic::linear_nobias", _linear_backward, setup_context=_linear_setup)
 
 
+# ------------------------------------------------------------------------------------- edge-reconstruction loss tail
+_register("edge_head_fwd", "(Tensor h_pre, Tensor w2, Tensor b2, Tensor? neg_valid, int n_pos, float slope) "
+          "-> (Tensor, Tensor, Tensor)",
+          lambda h_pre, w2, b2, neg_valid, n_pos, slope: _lib.edge_head_fwd(h_pre, w2, b2, neg_valid, n_pos, slope),
+          lambda h_pre, w2, b2, neg_valid, n_pos, slope:
+          (h_pre.new_empty(1), h_pre.new_empty(h_pre.shape[0]), h_pre.new_empty(1)))
+_register("edge_head_bwd", "(Tensor h_pre, Tensor w2, Tensor d_logit, Tensor weight_sum, Tensor grad_out, float slope) "
+          "-> (Tensor, Tensor, Tensor)",
+          lambda h_pre, w2, d_logit, weight_sum, grad_out, slope:
+          _lib.edge_head_bwd(h_pre, w2, d_logit, weight_sum, grad_out, slope),
+          lambda h_pre, w2, d_logit, weight_sum, grad_out, slope:
+          (h_pre.new_empty(h_pre.shape), h_pre.new_empty(h_pre.shape[1]), h_pre.new_empty(1)))
+
+
 # ------------------------------------------------------------------------------------- KNN, read-out
 def _knn_fake(train, query, k, index_offset):
     q = query.shape[0]

@@ -491,3 +491,41 @@ def test_edge_type_cache_follows_tensor_identity_and_endpoints_are_checked(cuda)
     bad = Graph(torch.tensor([0, 1], device=cuda), torch.tensor([1, -1], device=cuda), 5)
     with pytest.raises(ValueError):
         bad.structure.ensure_csr()                                    # device endpoints: checked before the sort
+
+
+@pytest.mark.parametrize("hidden,n_pos,n_neg,weighted", [(64, 300, 375, True), (256, 1000, 1250, True),
+                                                        (64, 37, 5, False), (128, 1, 0, False)])
+def test_edge_reconstruction_loss_tail_equals_tensor_path(cuda, hidden, n_pos, n_neg, weighted):
+    """magic_edge_head_fwd / _bwd (LeakyReLU -> Linear(hidden, 1) -> Sigmoid -> BCE in two passes) against the
+    same head evaluated with tensor operations in float64: loss, gradients of the gathered rows, of both linear
+    layers and their biases; negative pairs weighted 0 / 1, a scaled upstream gradient, and saturated logits
+    (the -100 clamp of BCELoss)."""
+    from magic_amd.model.autoencoder import GMAEModel
+    torch.manual_seed(hidden + n_pos)
+    layers = 2
+    m = GMAEModel(8, 4, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(cuda)
+    P = n_pos + n_neg
+    rows = torch.randn(2 * P, hidden * layers).to(cuda).requires_grad_(True)
+    valid = (torch.rand(n_neg) > 0.3).to(cuda) if weighted else None
+    with torch.no_grad():                      # two pairs far into saturation in float32 and float64 alike
+        rows[0] *= 1e4
+        rows[P - 1] *= -1e4
+    loss = m._edge_recon_loss(rows, n_pos, n_neg, valid)
+    assert loss is not None and loss.shape == ()
+    (loss * 0.25).backward()
+    got = dict(rows=rows.grad.clone(), **{n: p.grad.clone() for n, p in m.edge_recon_fc.named_parameters()})
+    # float64 evaluation of the reference's statements (model/autoencoder.py:257-266)
+    ref = copy.deepcopy(m.edge_recon_fc).double().cpu()
+    r64 = rows.detach().double().cpu().requires_grad_(True)
+    y_pred = ref(torch.cat([r64[:P], r64[P:]], dim=-1)).squeeze(-1)
+    y = torch.cat([torch.ones(n_pos), torch.zeros(n_neg)]).double()
+    if weighted:
+        w = torch.cat([torch.ones(n_pos), valid.cpu().double()])
+        want = torch.nn.functional.binary_cross_entropy(y_pred, y, weight=w, reduction="sum") / w.sum()
+    else:
+        want = torch.nn.BCELoss()(y_pred, y)
+    (want * 0.25).backward()
+    assert abs(float(loss) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
+    assert rel_err(got["rows"].cpu().double(), r64.grad) < 5e-5
+    for n, p in ref.named_parameters():
+        assert rel_err(got[n].cpu().double(), p.grad) < 5e-5, n
