@@ -324,7 +324,7 @@ def gat_leg(args, workload, steps, warmup, world, rank, dev):
             e2e_opt = create_optimizer("adam", e2e_model, 1e-3, 5e-4)   # train.py:82 with utils/config.py defaults
             pool = [(p_, 0) for p_ in parts]
             loader = [list(range(batch_graphs))]
-            batch_level_train(e2e_model, pool, loader * 4, e2e_opt, 1, dev, n_dim, e_dim, progress=False)
+            batch_level_train(e2e_model, pool, loader * 8, e2e_opt, 1, dev, n_dim, e_dim, progress=False)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             batch_level_train(e2e_model, pool, loader * 16, e2e_opt, 1, dev, n_dim, e_dim, progress=False)

@@ -238,6 +238,22 @@ int magic_fold_bwd(int32_t n_heads, int32_t head_dim, int32_t head_dim_padded, i
                    float *d_attn_t, float *d_w_res, float *d_w_efc, float *d_attn_e, float *d_bias,
                    void *stream);
 
+/* The same two maps for every layer of a model in one launch each (a HOST array of n_layers
+ * entries; the pointers travel by value in the kernel arguments, 8 layers per launch).  _fwd
+ * reads the inputs and writes w_aug / table / bias_p; _bwd reads the inputs and d_w_aug /
+ * d_table / d_bias_p (NULL = zero) and writes the d_* outputs (d_w_res / d_bias NULL for a layer
+ * without residual projection / bias).  Element for element what the per-layer calls produce. */
+typedef struct magic_fold_layer {
+    int32_t H, D, Dp, F, e_dim;     /* heads, head width, padded head width, input width, edge types */
+    int32_t reserved;
+    const float *w_fc, *attn_h, *attn_t, *w_res, *w_efc, *attn_e, *bias;
+    float *w_aug, *table, *bias_p;
+    const float *d_w_aug, *d_table, *d_bias_p;
+    float *d_w_fc, *d_attn_h, *d_attn_t, *d_w_res, *d_w_efc, *d_attn_e, *d_bias;
+} magic_fold_layer;
+int magic_fold_fwd_multi(int32_t n_layers, const magic_fold_layer *layers, void *stream);
+int magic_fold_bwd_multi(int32_t n_layers, const magic_fold_layer *layers, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Backward of magic_gat_fwd (DGL's EdgeSoftmax / GSpMM / GSDDMM backward + the PReLU,
  * bias and residual adjoints that torch autograd runs for model/gat.py:302-335).

@@ -60,6 +60,8 @@ SYMBOLS = {
     "magic_dropout_mask_dev": (c_i32, [c_i64, c_f32, c_vp, c_vp, c_vp]),
     "magic_fold_fwd": (c_i32, [c_i32] * 5 + [c_vp] * 10 + [c_vp]),
     "magic_fold_bwd": (c_i32, [c_i32] * 5 + [c_vp] * 15 + [c_vp]),
+    "magic_fold_fwd_multi": (c_i32, [c_i32, c_vp, c_vp]),
+    "magic_fold_bwd_multi": (c_i32, [c_i32, c_vp, c_vp]),
     "magic_gat_fwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "magic_gat_fwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, c_vp,
                               c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp,
@@ -491,6 +493,61 @@ def fold_bwd(H: int, D: int, Dp: int, w_fc, attn_h, attn_t, w_efc, attn_e, d_w_a
                               _dev(d_w_aug), _dev(d_table), _dev(d_bias_p), _dev(d_w_fc), _dev(d_ah), _dev(d_at),
                               _dev(d_w_res), _dev(d_w_efc), _dev(d_ae), _dev(d_bias), _stream()), "magic_fold_bwd")
     return d_w_fc, d_ah, d_at, d_w_res, d_w_efc, d_ae, d_bias
+
+
+class MagicFoldLayer(C.Structure):
+    """``magic_fold_layer`` of include/magic_hip.h."""
+    _fields_ = [(n, c_i32) for n in ("H", "D", "Dp", "F", "e_dim", "reserved")] + \
+               [(n, c_vp) for n in ("w_fc", "attn_h", "attn_t", "w_res", "w_efc", "attn_e", "bias", "w_aug", "table",
+                                    "bias_p", "d_w_aug", "d_table", "d_bias_p", "d_w_fc", "d_attn_h", "d_attn_t",
+                                    "d_w_res", "d_w_efc", "d_attn_e", "d_bias")]
+
+
+def _fold_slots(layers):
+    """ctypes array for ``layers`` = [(H, D, Dp, w_fc, attn_h, attn_t, w_res, w_efc, attn_e, bias), ...]."""
+    arr = (MagicFoldLayer * len(layers))()
+    for sl, (H, D, Dp, w_fc, attn_h, attn_t, w_res, w_efc, attn_e, bias) in zip(arr, layers):
+        sl.H, sl.D, sl.Dp, sl.F, sl.e_dim = H, D, Dp, w_fc.shape[1], w_efc.shape[1]
+        sl.w_fc, sl.attn_h, sl.attn_t = _dev(w_fc, torch.float32, "w_fc"), _dev(attn_h), _dev(attn_t)
+        sl.w_res, sl.w_efc, sl.attn_e, sl.bias = _dev(w_res), _dev(w_efc), _dev(attn_e), _dev(bias)
+    return arr
+
+
+def fold_fwd_multi(layers):
+    """``fold_fwd`` for every layer of ``layers`` (see ``_fold_slots``) in one launch; returns
+    [(w_aug, table, bias_p | None), ...]."""
+    arr = _fold_slots(layers)
+    outs = []
+    for sl, (H, D, Dp, w_fc, attn_h, attn_t, w_res, w_efc, attn_e, bias) in zip(arr, layers):
+        dev, Cp = w_fc.device, H * Dp
+        rows = Cp + 2 * H + (Cp if w_res is not None else 0)
+        w_aug = torch.empty(rows, sl.F, dtype=torch.float32, device=dev)
+        table = torch.empty(sl.e_dim, H, dtype=torch.float32, device=dev)
+        bias_p = torch.empty(Cp, dtype=torch.float32, device=dev) if bias is not None else None
+        sl.w_aug, sl.table, sl.bias_p = _dev(w_aug), _dev(table), _dev(bias_p)
+        outs.append((w_aug, table, bias_p))
+    _check(load().magic_fold_fwd_multi(len(layers), C.cast(arr, c_vp), _stream()), "magic_fold_fwd_multi")
+    return outs
+
+
+def fold_bwd_multi(layers, grads):
+    """``fold_bwd`` for every layer in one launch; ``grads`` = [(d_w_aug | None, d_table | None, d_bias_p | None),
+    ...]; returns [(d_w_fc, d_attn_h, d_attn_t, d_w_res | None, d_w_efc, d_attn_e, d_bias | None), ...]."""
+    arr = _fold_slots(layers)
+    outs = []
+    for sl, (H, D, Dp, w_fc, attn_h, attn_t, w_res, w_efc, attn_e, bias), (d_w_aug, d_table, d_bias_p) in \
+            zip(arr, layers, grads):
+        dev, Cn = w_fc.device, H * D
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+        d_w_fc, d_ah, d_at, d_w_efc, d_ae = new(Cn, sl.F), new(1, H, D), new(1, H, D), new(Cn, sl.e_dim), new(1, H, D)
+        d_w_res = new(Cn, sl.F) if w_res is not None else None
+        d_bias = new(1, H, D) if bias is not None else None
+        sl.d_w_aug, sl.d_table, sl.d_bias_p = _dev(d_w_aug), _dev(d_table), _dev(d_bias_p)
+        sl.d_w_fc, sl.d_attn_h, sl.d_attn_t, sl.d_w_res = _dev(d_w_fc), _dev(d_ah), _dev(d_at), _dev(d_w_res)
+        sl.d_w_efc, sl.d_attn_e, sl.d_bias = _dev(d_w_efc), _dev(d_ae), _dev(d_bias)
+        outs.append((d_w_fc, d_ah, d_at, d_w_res, d_w_efc, d_ae, d_bias))
+    _check(load().magic_fold_bwd_multi(len(layers), C.cast(arr, c_vp), _stream()), "magic_fold_bwd_multi")
+    return outs
 
 
 # ------------------------------------------------------------------------------------- GAT

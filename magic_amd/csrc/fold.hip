@@ -19,7 +19,7 @@ struct FoldArgs {
     float *d_w_fc, *d_attn_h, *d_attn_t, *d_w_res, *d_w_efc, *d_attn_e, *d_bias;
 };
 
-__global__ __launch_bounds__(256) void k_fold_fwd(FoldArgs a) {
+__device__ __forceinline__ void fold_fwd_body(const FoldArgs &a) {
     const int H = a.H, D = a.D, Dp = a.Dp, F = a.F;
     const int Cp = H * Dp;
     const int rows = Cp + 2 * H + (a.has_res ? Cp : 0);
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_fold_fwd(FoldArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_fold_bwd(FoldArgs a) {
+__device__ __forceinline__ void fold_bwd_body(const FoldArgs &a) {
     const int H = a.H, D = a.D, Dp = a.Dp, F = a.F, C = H * D, Cp = H * Dp;
     const float *dh = a.d_w_aug + (int64_t)Cp * F;        // [H,F] gradient of the attn_h fold rows
     const float *dt = a.d_w_aug + (int64_t)(Cp + H) * F;  // [H,F]
@@ -105,7 +105,73 @@ __global__ __launch_bounds__(256) void k_fold_bwd(FoldArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_fold_fwd(FoldArgs a) { fold_fwd_body(a); }
+__global__ __launch_bounds__(256) void k_fold_bwd(FoldArgs a) { fold_bwd_body(a); }
+
+// every layer of a model in one launch: blockIdx.y = layer (the arguments of up to 8 layers travel by value)
+constexpr int FOLD_BATCH = 8;
+struct FoldBatch {
+    FoldArgs layer[FOLD_BATCH];
+};
+static_assert(sizeof(FoldBatch) <= 3584, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(256) void k_fold_fwd_multi(FoldBatch b) { fold_fwd_body(b.layer[blockIdx.y]); }
+__global__ __launch_bounds__(256) void k_fold_bwd_multi(FoldBatch b) { fold_bwd_body(b.layer[blockIdx.y]); }
+
 bool dims_ok(int H, int D, int Dp, int F, int e_dim) { return H > 0 && D > 0 && Dp >= D && F > 0 && e_dim > 0; }
+
+int64_t fwd_items(const FoldArgs &a) {
+    const int Cp = a.H * a.Dp;
+    return (int64_t)(Cp + 2 * a.H + (a.has_res ? Cp : 0)) * a.F + (int64_t)a.e_dim * a.H + (a.has_bias ? Cp : 0);
+}
+
+int bwd_grid(const FoldArgs &a) {
+    const int C = a.H * a.D;
+    const int64_t n = (int64_t)C * a.F * (a.has_res ? 2 : 1) + (int64_t)C * a.e_dim + (int64_t)C * (a.has_bias ? 4 : 3);
+    int grid = magic::stride_grid(n, 256, 1024);
+    const int dot_blocks = (3 * C + 3) / 4;  // one wave per dot product
+    if (grid < dot_blocks) grid = dot_blocks < 1024 ? dot_blocks : 1024;
+    return grid;
+}
+
+bool from_layer(const magic_fold_layer &l, bool backward, FoldArgs *a) {
+    if (!dims_ok(l.H, l.D, l.Dp, l.F, l.e_dim)) return false;
+    if (!l.w_fc || !l.attn_h || !l.attn_t || !l.w_efc || !l.attn_e) return false;
+    *a = FoldArgs{};
+    a->H = l.H, a->D = l.D, a->Dp = l.Dp, a->F = l.F, a->e_dim = l.e_dim;
+    a->w_fc = l.w_fc, a->attn_h = l.attn_h, a->attn_t = l.attn_t, a->w_efc = l.w_efc, a->attn_e = l.attn_e;
+    if (!backward) {
+        if (!l.w_aug || !l.table || (l.bias && !l.bias_p)) return false;
+        a->has_res = l.w_res != nullptr, a->has_bias = l.bias != nullptr;
+        a->w_res = l.w_res, a->bias = l.bias, a->w_aug = l.w_aug, a->table = l.table, a->bias_p = l.bias_p;
+    } else {
+        if (!l.d_w_fc || !l.d_attn_h || !l.d_attn_t || !l.d_w_efc || !l.d_attn_e) return false;
+        a->has_res = l.d_w_res != nullptr, a->has_bias = l.d_bias != nullptr;
+        a->d_w_aug = l.d_w_aug, a->d_table = l.d_table, a->d_bias_p = l.d_bias_p;
+        a->d_w_fc = l.d_w_fc, a->d_attn_h = l.d_attn_h, a->d_attn_t = l.d_attn_t, a->d_w_res = l.d_w_res;
+        a->d_w_efc = l.d_w_efc, a->d_attn_e = l.d_attn_e, a->d_bias = l.d_bias;
+    }
+    return true;
+}
+
+int fold_multi(int32_t n_layers, const magic_fold_layer *layers, bool backward, hipStream_t stream) {
+    if (n_layers < 0 || (n_layers > 0 && !layers)) return MAGIC_ERR_INVALID_ARG;
+    for (int32_t l0 = 0; l0 < n_layers; l0 += FOLD_BATCH) {
+        FoldBatch b;
+        const int nb = n_layers - l0 < FOLD_BATCH ? n_layers - l0 : FOLD_BATCH;
+        int grid = 1;
+        for (int i = 0; i < nb; ++i) {
+            if (!from_layer(layers[l0 + i], backward, &b.layer[i])) return MAGIC_ERR_INVALID_ARG;
+            const int g = backward ? bwd_grid(b.layer[i]) : magic::stride_grid(fwd_items(b.layer[i]), 256, 1024);
+            if (g > grid) grid = g;
+        }
+        for (int i = nb; i < FOLD_BATCH; ++i) b.layer[i] = b.layer[0];  // (never indexed: gridDim.y = nb)
+        if (backward)
+            MAGIC_LAUNCH("fold_bwd", k_fold_bwd_multi, dim3(grid, nb), 256, 0, stream, b);
+        else
+            MAGIC_LAUNCH("fold_fwd", k_fold_fwd_multi, dim3(grid, nb), 256, 0, stream, b);
+    }
+    return magic::launch_status();
+}
 
 }  // namespace
 
@@ -149,6 +215,14 @@ int magic_fold_bwd(int32_t H, int32_t D, int32_t Dp, int32_t F, int32_t e_dim, c
     if (grid < dot_blocks) grid = dot_blocks < 1024 ? dot_blocks : 1024;
     MAGIC_LAUNCH("fold_bwd", k_fold_bwd, grid, 256, 0, (hipStream_t)stream_, a);
     return magic::launch_status();
+}
+
+int magic_fold_fwd_multi(int32_t n_layers, const magic_fold_layer *layers, void *stream) {
+    return fold_multi(n_layers, layers, false, (hipStream_t)stream);
+}
+
+int magic_fold_bwd_multi(int32_t n_layers, const magic_fold_layer *layers, void *stream) {
+    return fold_multi(n_layers, layers, true, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -25,7 +25,7 @@ from .. import _lib, ops
 from ..graph import Graph
 from ..utils.utils import create_norm, sample_range
 from .fused import FusedCfg, FusedGMAEFn
-from .gat import GAT, _LinearFn, _pad_head_dim, linear_nobias
+from .gat import GAT, _LinearFn, _pad_head_dim, fold_layers, linear_nobias
 from .loss_func import sce_loss, sce_loss_masked
 
 
@@ -353,11 +353,14 @@ class GMAEModel(nn.Module):
 
         cfg = self._fused_cfg(use_g, drop_masks, drop_seeds) if fused else None
         if cfg is not None:
+            # operands of every layer from one launch (and their adjoints from one launch in backward)
+            enc_layers = list(self.encoder.gats)
+            folded = fold_layers(enc_layers + [self.decoder.gats[0]], [cfg.D] * len(enc_layers) + [cfg.Dp])
             params = []
-            for layer in self.encoder.gats:
-                params += list(layer.fused_params(cfg.D))
+            for layer, (w_aug, table, bias) in zip(enc_layers, folded):
+                params += [w_aug, table, bias, layer.activation.weight]
             params.append(self.encoder_to_decoder.weight)
-            params += list(self.decoder.gats[0].fused_params(cfg.Dp))[:3]
+            params += list(folded[-1])
             if feat_has_grad:
                 enc_rep, recon_p, samples = FusedGMAEFn.apply(pre_use_x, sample_idx, cfg, None, *params)
             else:

@@ -71,6 +71,48 @@ class _FoldFn(torch.autograd.Function):
         return d_w_fc, d_ah, d_at, d_w_res, d_w_efc, d_ae, d_bias, None, None, None
 
 
+class _FoldAllFn(torch.autograd.Function):
+    """``_FoldFn`` for several layers at once: one launch forward, one backward.  Inputs: ``dims`` = [(H, D,
+    Dp), ...] and seven tensors per layer (``w_fc, attn_h, attn_t, w_res | None, w_efc, attn_e, bias | None``);
+    outputs: three per layer (``w_aug, table, bias_p | None``)."""
+
+    @staticmethod
+    def forward(ctx, dims, *tensors):
+        c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        layers = [tuple(d) + tuple(map(c, tensors[7 * i:7 * i + 7])) for i, d in enumerate(dims)]
+        outs = _lib.fold_fwd_multi(layers)
+        ctx.layers = [(H, D, Dp, None, None, None, w_res is not None, None, None, bias is not None)
+                      for (H, D, Dp, _w, _a, _b, w_res, _e, _f, bias) in layers]
+        ctx.save_for_backward(*[t for lay in layers for t in (lay[3], lay[4], lay[5], lay[7], lay[8])])
+        ctx.set_materialize_grads(False)
+        return tuple(t for out in outs for t in out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        saved = ctx.saved_tensors
+        c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        layers = []
+        for i, (H, D, Dp, _1, _2, _3, has_res, _4, _5, has_bias) in enumerate(ctx.layers):
+            w_fc, attn_h, attn_t, w_efc, attn_e = saved[5 * i:5 * i + 5]
+            # (the residual weight / bias themselves are not read by the adjoint: only whether they exist)
+            layers.append((H, D, Dp, w_fc, attn_h, attn_t, w_fc if has_res else None, w_efc, attn_e,
+                           attn_h if has_bias else None))
+        outs = _lib.fold_bwd_multi(layers, [tuple(map(c, grads[3 * i:3 * i + 3])) for i in range(len(layers))])
+        return (None,) + tuple(t for out in outs for t in out)
+
+
+def fold_layers(layers, pads):
+    """(augmented weight, edge score table, flat bias | None) of every ``GATConv`` in ``layers`` (head widths
+    padded to ``pads``) from one launch."""
+    dims, tensors = [], []
+    for layer, Dp in zip(layers, pads):
+        dims.append((layer.n_heads, layer.out_feat, Dp))
+        res_w = layer.res_fc.weight if isinstance(layer.res_fc, nn.Linear) else None
+        tensors += [layer.fc.weight, layer.attn_h, layer.attn_t, res_w, layer.edge_fc.weight, layer.attn_e, layer.bias]
+    out = _FoldAllFn.apply(dims, *tensors)
+    return [tuple(out[3 * i:3 * i + 3]) for i in range(len(dims))]
+
+
 class _GATLayerFn(torch.autograd.Function):
     """proj GEMM + fused edge phase; backward = HIP edge-phase backward + two GEMMs."""
 
