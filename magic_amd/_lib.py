@@ -41,10 +41,10 @@ SYMBOLS = {
                                  c_vp, c_sz, c_vp]),
     "magic_negative_filter": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "magic_edge_head_workspace_bytes": (c_sz, [c_i64, c_i32]),
-    "magic_edge_head_fwd": (c_i32, [c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp,
+    "magic_edge_head_fwd": (c_i32, [c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp,
                                     c_vp, c_sz, c_vp]),
-    "magic_edge_head_bwd": (c_i32, [c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_vp,
-                                    c_vp, c_sz, c_vp]),
+    "magic_edge_head_bwd": (c_i32, [c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp,
+                                    c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_adam_step": (c_i32, [c_i32, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "magic_proj_fwd": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_i64,
                                c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
@@ -237,13 +237,15 @@ def walk_order(ptrs, light_max: int):
     return outs
 
 
-def edge_head_fwd(h_pre: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, neg_valid: Optional[torch.Tensor],
-                  n_pos: int, slope: float):
-    """Returns (loss [1], d_logit [P] before the division by the weight sum, weight_sum [1])."""
+def edge_head_fwd(h_pre: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor, b2: torch.Tensor,
+                  neg_valid: Optional[torch.Tensor], n_pos: int, slope: float):
+    """Returns (loss [1], d_logit [P] before the division by the weight sum, weight_sum [1]); ``b1`` is the
+    first layer's bias when ``h_pre`` comes without it."""
     lib = load()
     P, W = h_pre.shape
     dev = h_pre.device
     h_pre, w2 = _rows(h_pre), w2.contiguous().view(-1)
+    b1 = None if b1 is None else b1.contiguous().view(-1)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     d_logit = torch.empty(P, dtype=torch.float32, device=dev)
     wsum = torch.empty(1, dtype=torch.float32, device=dev)
@@ -253,30 +255,34 @@ def edge_head_fwd(h_pre: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, neg_v
             raise MagicHipError("neg_valid must be a bool / uint8 tensor with one entry per negative pair")
     ws = workspace(lib.magic_edge_head_workspace_bytes(P, W), dev)
     _check(lib.magic_edge_head_fwd(P, int(n_pos), W, _dev(h_pre, torch.float32, "h_pre"), h_pre.stride(0),
-                                   _dev(w2, torch.float32, "w2"), _dev(b2, torch.float32, "b2"), _dev(neg_valid),
-                                   float(slope), _dev(loss), _dev(d_logit), _dev(wsum), ws.data_ptr(), ws.numel(),
-                                   _stream()), "magic_edge_head_fwd")
+                                   _dev(b1, torch.float32, "b1"), _dev(w2, torch.float32, "w2"),
+                                   _dev(b2, torch.float32, "b2"), _dev(neg_valid), float(slope), _dev(loss),
+                                   _dev(d_logit), _dev(wsum), ws.data_ptr(), ws.numel(), _stream()),
+           "magic_edge_head_fwd")
     return loss, d_logit, wsum
 
 
-def edge_head_bwd(h_pre: torch.Tensor, w2: torch.Tensor, d_logit: torch.Tensor, wsum: torch.Tensor,
-                  grad_out: torch.Tensor, slope: float):
-    """Returns (d_h_pre [P, W], d_w2 [W], d_b2 [1])."""
+def edge_head_bwd(h_pre: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor, d_logit: torch.Tensor,
+                  wsum: torch.Tensor, grad_out: torch.Tensor, slope: float):
+    """Returns (d_h_pre [P, W], d_b1 [W] | None, d_w2 [W], d_b2 [1])."""
     lib = load()
     P, W = h_pre.shape
     dev = h_pre.device
     h_pre, w2 = _rows(h_pre), w2.contiguous().view(-1)
+    b1 = None if b1 is None else b1.contiguous().view(-1)
     grad_out = grad_out.contiguous().view(-1)
     d_h = torch.empty(P, W, dtype=torch.float32, device=dev)
     d_w2 = torch.empty(W, dtype=torch.float32, device=dev)
     d_b2 = torch.empty(1, dtype=torch.float32, device=dev)
+    d_b1 = torch.empty(W, dtype=torch.float32, device=dev) if b1 is not None else None
     ws = workspace(lib.magic_edge_head_workspace_bytes(P, W), dev)
     _check(lib.magic_edge_head_bwd(P, W, _dev(h_pre, torch.float32, "h_pre"), h_pre.stride(0),
-                                   _dev(w2, torch.float32, "w2"), _dev(d_logit, torch.float32, "d_logit"),
-                                   _dev(wsum, torch.float32, "weight_sum"), _dev(grad_out, torch.float32, "grad_out"),
-                                   float(slope), _dev(d_h), d_h.stride(0), _dev(d_w2), _dev(d_b2), ws.data_ptr(),
-                                   ws.numel(), _stream()), "magic_edge_head_bwd")
-    return d_h, d_w2, d_b2
+                                   _dev(b1, torch.float32, "b1"), _dev(w2, torch.float32, "w2"),
+                                   _dev(d_logit, torch.float32, "d_logit"), _dev(wsum, torch.float32, "weight_sum"),
+                                   _dev(grad_out, torch.float32, "grad_out"), float(slope), _dev(d_h), d_h.stride(0),
+                                   _dev(d_b1), _dev(d_w2), _dev(d_b2), ws.data_ptr(), ws.numel(), _stream()),
+           "magic_edge_head_bwd")
+    return d_h, d_b1, d_w2, d_b2
 
 
 class MagicAdamSlot(C.Structure):

@@ -120,12 +120,13 @@ class _PairLinearFn(torch.autograd.Function):
         ctx.lib_gemm = lib_gemm = bool(lib_gemm) and n_pairs > 0
         if not lib_gemm:
             ctx.save_for_backward(rows, w[:, :width], w[:, width:])
-            out = torch.addmm(b, rows[:n_pairs], w[:, :width].t())
+            out = torch.mm(rows[:n_pairs], w[:, :width].t()) if b is None else torch.addmm(b, rows[:n_pairs], w[:, :width].t())
             return out.addmm_(rows[n_pairs:], w[:, width:].t())
         wa, wb = w[:, :width].contiguous(), w[:, width:].contiguous()
         ctx.save_for_backward(rows, wa, wb)
         out = ops.proj_fwd(rows[:n_pairs], wa, w.shape[0], 0, 0)[0]
-        return out.add_(ops.proj_fwd(rows[n_pairs:], wb, w.shape[0], 0, 0)[0]).add_(b)
+        out.add_(ops.proj_fwd(rows[n_pairs:], wb, w.shape[0], 0, 0)[0])
+        return out if b is None else out.add_(b)
 
     @staticmethod
     def backward(ctx, g):
@@ -149,24 +150,26 @@ class _PairLinearFn(torch.autograd.Function):
 
 
 class _EdgeHeadLossFn(torch.autograd.Function):
-    """``BCELoss(Sigmoid(Linear(LeakyReLU(h_pre))), [1]*n_pos + [0]*n_neg)`` with the negative pairs weighted by
-    ``neg_valid`` -- the tail of the edge-reconstruction loss (``model/autoencoder.py:257-266`` through the head
-    of ``:114-119``) as two passes over ``h_pre`` (``magic_edge_head_fwd`` / ``_bwd``) instead of ~25 small
-    tensor operations."""
+    """``BCELoss(Sigmoid(Linear(LeakyReLU(h + b1))), [1]*n_pos + [0]*n_neg)`` with the negative pairs weighted
+    by ``neg_valid`` -- the tail of the edge-reconstruction loss (``model/autoencoder.py:257-266`` through the
+    head of ``:114-119``) as two passes over ``h`` (``magic_edge_head_fwd`` / ``_bwd``) instead of ~25 small
+    tensor operations.  ``h`` is the first layer's output without its bias ``b1``."""
 
     @staticmethod
-    def forward(ctx, h_pre, w2, b2, neg_valid, n_pos, slope):
-        loss, d_logit, wsum = torch.ops.magic.edge_head_fwd(h_pre, w2, b2, neg_valid, int(n_pos), float(slope))
-        ctx.save_for_backward(h_pre, w2, d_logit, wsum)
+    def forward(ctx, h, b1, w2, b2, neg_valid, n_pos, slope):
+        loss, d_logit, wsum = torch.ops.magic.edge_head_fwd(h, b1, w2, b2, neg_valid, int(n_pos), float(slope))
+        ctx.save_for_backward(h, b1, w2, d_logit, wsum)
         ctx.slope = float(slope)
         ctx.w2_shape, ctx.b2_shape = w2.shape, b2.shape
         return loss.view(())
 
     @staticmethod
     def backward(ctx, g):
-        h_pre, w2, d_logit, wsum = ctx.saved_tensors
-        d_h, d_w2, d_b2 = torch.ops.magic.edge_head_bwd(h_pre, w2, d_logit, wsum, g.contiguous().float(), ctx.slope)
-        return d_h, d_w2.view(ctx.w2_shape), d_b2.view(ctx.b2_shape), None, None, None
+        h, b1, w2, d_logit, wsum = ctx.saved_tensors
+        d_h, d_b1, d_w2, d_b2 = torch.ops.magic.edge_head_bwd(h, b1, w2, d_logit, wsum, g.contiguous().float(),
+                                                               ctx.slope)
+        return d_h, (d_b1.view(b1.shape) if b1 is not None else None), d_w2.view(ctx.w2_shape), \
+            d_b2.view(ctx.b2_shape), None, None, None
 
 
 class GMAEModel(nn.Module):
@@ -308,8 +311,8 @@ class GMAEModel(nn.Module):
             neg_valid = torch.as_tensor(neg_valid).to(rows.device)
             if neg_valid.dtype not in (torch.bool, torch.uint8):
                 neg_valid = neg_valid != 0
-        h_pre = _PairLinearFn.apply(rows, n_pos + n_neg, fc1.weight, fc1.bias, True)
-        return _EdgeHeadLossFn.apply(h_pre, fc2.weight, fc2.bias, neg_valid, n_pos, act.negative_slope)
+        h = _PairLinearFn.apply(rows, n_pos + n_neg, fc1.weight, None, True)   # (the bias joins in the tail)
+        return _EdgeHeadLossFn.apply(h, fc1.bias, fc2.weight, fc2.bias, neg_valid, n_pos, act.negative_slope)
 
     def _edge_recon(self, rows, n_pairs, lib_gemm=False):
         """``edge_recon_fc`` (``model/autoencoder.py:75-78``) on the pairs (row i, row n_pairs + i) of

@@ -304,17 +304,24 @@ torch.library.register_autograd("magic::linear_nobias", _linear_backward, setup_
 
 
 # ------------------------------------------------------------------------------------- edge-reconstruction loss tail
-_register("edge_head_fwd", "(Tensor h_pre, Tensor w2, Tensor b2, Tensor? neg_valid, int n_pos, float slope) "
+_register("edge_head_fwd", "(Tensor h_pre, Tensor? b1, Tensor w2, Tensor b2, Tensor? neg_valid, int n_pos, float slope) "
           "-> (Tensor, Tensor, Tensor)",
-          lambda h_pre, w2, b2, neg_valid, n_pos, slope: _lib.edge_head_fwd(h_pre, w2, b2, neg_valid, n_pos, slope),
-          lambda h_pre, w2, b2, neg_valid, n_pos, slope:
+          lambda h_pre, b1, w2, b2, neg_valid, n_pos, slope:
+          _lib.edge_head_fwd(h_pre, b1, w2, b2, neg_valid, n_pos, slope),
+          lambda h_pre, b1, w2, b2, neg_valid, n_pos, slope:
           (h_pre.new_empty(1), h_pre.new_empty(h_pre.shape[0]), h_pre.new_empty(1)))
-_register("edge_head_bwd", "(Tensor h_pre, Tensor w2, Tensor d_logit, Tensor weight_sum, Tensor grad_out, float slope) "
-          "-> (Tensor, Tensor, Tensor)",
-          lambda h_pre, w2, d_logit, weight_sum, grad_out, slope:
-          _lib.edge_head_bwd(h_pre, w2, d_logit, weight_sum, grad_out, slope),
-          lambda h_pre, w2, d_logit, weight_sum, grad_out, slope:
-          (h_pre.new_empty(h_pre.shape), h_pre.new_empty(h_pre.shape[1]), h_pre.new_empty(1)))
+
+
+def _edge_head_bwd(h_pre, b1, w2, d_logit, weight_sum, grad_out, slope: float):
+    d_h, d_b1, d_w2, d_b2 = _lib.edge_head_bwd(h_pre, b1, w2, d_logit, weight_sum, grad_out, slope)
+    return d_h, d_b1 if d_b1 is not None else _empty(h_pre), d_w2, d_b2
+
+
+_register("edge_head_bwd", "(Tensor h_pre, Tensor? b1, Tensor w2, Tensor d_logit, Tensor weight_sum, Tensor grad_out, "
+          "float slope) -> (Tensor, Tensor, Tensor, Tensor)", _edge_head_bwd,
+          lambda h_pre, b1, w2, d_logit, weight_sum, grad_out, slope:
+          (h_pre.new_empty(h_pre.shape), h_pre.new_empty(h_pre.shape[1] if b1 is not None else 0),
+           h_pre.new_empty(h_pre.shape[1]), h_pre.new_empty(1)))
 
 
 # ------------------------------------------------------------------------------------- KNN, read-out

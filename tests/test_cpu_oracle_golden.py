@@ -451,10 +451,10 @@ def test_custom_ops_are_registered_with_schemas_and_fake_kernels():
         ok = torch.ops.magic.negative_filter(plan[0], torch.empty(e, **i32), plan[0], torch.empty(e, **i32),
                                              torch.empty(125, **i64), torch.empty(125, **i64), 100)
         assert ok.shape == (125,) and ok.dtype == torch.bool
-        loss, d_logit, wsum = torch.ops.magic.edge_head_fwd(f(225, 64), f(1, 64), f(1), None, 100, 0.2)
+        loss, d_logit, wsum = torch.ops.magic.edge_head_fwd(f(225, 64), f(64), f(1, 64), f(1), None, 100, 0.2)
         assert loss.shape == (1,) and d_logit.shape == (225,) and wsum.shape == (1,)
-        d_h, d_w2, d_b2 = torch.ops.magic.edge_head_bwd(f(225, 64), f(1, 64), d_logit, wsum, f(1), 0.2)
-        assert d_h.shape == (225, 64) and d_w2.shape == (64,) and d_b2.shape == (1,)
+        d_h, d_b1, d_w2, d_b2 = torch.ops.magic.edge_head_bwd(f(225, 64), f(64), f(1, 64), d_logit, wsum, f(1), 0.2)
+        assert d_h.shape == (225, 64) and d_b1.shape == (64,) and d_w2.shape == (64,) and d_b2.shape == (1,)
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.magic.knn_topk(torch.zeros(10, 4), torch.zeros(2, 4), 1, 0)
 

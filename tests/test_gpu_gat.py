@@ -508,6 +508,8 @@ def test_edge_reconstruction_loss_tail_equals_tensor_path(cuda, hidden, n_pos, n
     rows = torch.randn(2 * P, hidden * layers).to(cuda).requires_grad_(True)
     valid = (torch.rand(n_neg) > 0.3).to(cuda) if weighted else None
     with torch.no_grad():                      # two pairs far into saturation in float32 and float64 alike
+        m.edge_recon_fc[0].bias.normal_()      # (zero-initialised by the model; the tail adds it on the fly)
+        m.edge_recon_fc[2].bias.fill_(0.3)
         rows[0] *= 1e4
         rows[P - 1] *= -1e4
     loss = m._edge_recon_loss(rows, n_pos, n_neg, valid)
