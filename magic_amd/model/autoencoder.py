@@ -21,7 +21,7 @@ from itertools import chain
 import torch
 import torch.nn as nn
 
-from .. import _lib, ops
+from .. import _lib, ops  # noqa: F401  (ops registers torch.ops.magic.*)
 from ..graph import Graph
 from ..utils.utils import create_norm, sample_range
 from .fused import FusedCfg, FusedGMAEFn
@@ -101,52 +101,6 @@ def global_uniform_negative_sampling(g: Graph, num_samples: int, generator: torc
     cannot be matched; parity tests inject the pairs instead."""
     u, v, ok = _negative_candidates(g, num_samples, generator)
     return u[ok], v[ok]
-
-
-class _PairLinearFn(torch.autograd.Function):
-    """First layer of the edge-reconstruction head on the pair matrix,
-    ``F.linear(torch.cat([h[src], h[dst]], dim=-1), w, b)`` (``model/autoencoder.py:257-258`` into
-    ``:75``), without forming the pair matrix: ``rows`` holds the P source rows then the P
-    destination rows, and ``[s | d] W^T = s Wa^T + d Wb^T`` with ``W = [Wa | Wb]``.  Backward writes
-    the two halves of the row gradient in place (autograd through slices and ``cat`` zero-fills and
-    adds full-size tensors).  The weight gradients run on the streaming dW kernel; with ``lib_gemm`` the
-    four other products run on the library's projection kernels (1.7 x the BLAS rate at hidden 256; on a
-    single small graph, where the step is bound by its launches, the six launches more measured no difference)."""
-
-    @staticmethod
-    def forward(ctx, rows, n_pairs, w, b, lib_gemm):
-        width = rows.shape[1]
-        ctx.n_pairs = n_pairs
-        ctx.lib_gemm = lib_gemm = bool(lib_gemm) and n_pairs > 0
-        if not lib_gemm:
-            ctx.save_for_backward(rows, w[:, :width], w[:, width:])
-            out = torch.mm(rows[:n_pairs], w[:, :width].t()) if b is None else torch.addmm(b, rows[:n_pairs], w[:, :width].t())
-            return out.addmm_(rows[n_pairs:], w[:, width:].t())
-        wa, wb = w[:, :width].contiguous(), w[:, width:].contiguous()
-        ctx.save_for_backward(rows, wa, wb)
-        out = ops.proj_fwd(rows[:n_pairs], wa, w.shape[0], 0, 0)[0]
-        out.add_(ops.proj_fwd(rows[n_pairs:], wb, w.shape[0], 0, 0)[0])
-        return out if b is None else out.add_(b)
-
-    @staticmethod
-    def backward(ctx, g):
-        rows, wa, wb = ctx.saved_tensors
-        n = ctx.n_pairs
-        g = g.contiguous()
-        d_rows = d_w = d_b = None
-        if ctx.needs_input_grad[0]:
-            d_rows = torch.empty_like(rows)
-            if ctx.lib_gemm:
-                ops.proj_bwd_input(g, wa, out=d_rows[:n])
-                ops.proj_bwd_input(g, wb, out=d_rows[n:])
-            else:
-                torch.mm(g, wa, out=d_rows[:n])
-                torch.mm(g, wb, out=d_rows[n:])
-        if ctx.needs_input_grad[2]:
-            d_w = torch.cat([ops.proj_bwd_weight(g, rows[:n]), ops.proj_bwd_weight(g, rows[n:])], dim=1)
-        if ctx.needs_input_grad[3]:
-            d_b = g.sum(0)
-        return d_rows, None, d_w, d_b, None
 
 
 class _EdgeHeadLossFn(torch.autograd.Function):
@@ -297,30 +251,30 @@ class GMAEModel(nn.Module):
         return FusedCfg(g.structure.ensure_csr(), etype, g.edge_types_csr(), enc[0].edge_feat, len(enc), H, D, d.out_feat,
                         _pad_head_dim(d.out_feat), enc[0].leaky_relu.negative_slope, res_kinds, masks, scale)
 
-    def _edge_recon_loss(self, rows, n_pos, n_neg, neg_valid):
-        """The BCE of ``model/autoencoder.py:257-266`` on the library's loss tail, or None when the head is not
-        the one the reference builds (``:114-119``) or the operands are not float32 rows on the GPU."""
+    def _edge_recon_loss(self, pairs, n_pos, n_neg, neg_valid):
+        """The BCE of ``model/autoencoder.py:257-266`` on the library: the head's first layer as one projection of
+        the pair matrix, the rest as the loss tail of ``csrc/head.hip``.  None when the head is not the one the
+        reference builds (``:114-119``) or the operands are not float32 rows on the GPU."""
         fc1, act, fc2, sig = self.edge_recon_fc
-        if not (rows.is_cuda and rows.dtype == torch.float32 and isinstance(act, nn.LeakyReLU)
+        if not (pairs.is_cuda and pairs.dtype == torch.float32 and isinstance(act, nn.LeakyReLU)
                 and isinstance(sig, nn.Sigmoid) and isinstance(fc2, nn.Linear) and fc2.out_features == 1
-                and fc2.bias is not None and fc2.in_features % 4 == 0 and fc2.in_features <= 1024
-                and isinstance(self.recon_loss, nn.BCELoss) and self.recon_loss.weight is None
-                and self.recon_loss.reduction == "mean" and n_pos + n_neg > 0):
+                and fc2.bias is not None and fc1.bias is not None and fc2.in_features % 4 == 0
+                and fc2.in_features <= 320 and isinstance(self.recon_loss, nn.BCELoss)
+                and self.recon_loss.weight is None and self.recon_loss.reduction == "mean" and n_pos + n_neg > 0):
             return None
         if neg_valid is not None:
-            neg_valid = torch.as_tensor(neg_valid).to(rows.device)
+            neg_valid = torch.as_tensor(neg_valid).to(pairs.device)
             if neg_valid.dtype not in (torch.bool, torch.uint8):
                 neg_valid = neg_valid != 0
-        h = _PairLinearFn.apply(rows, n_pos + n_neg, fc1.weight, None, True)   # (the bias joins in the tail)
+        h = linear_nobias(pairs, fc1.weight)                                   # (the bias joins in the tail)
         return _EdgeHeadLossFn.apply(h, fc1.bias, fc2.weight, fc2.bias, neg_valid, n_pos, act.negative_slope)
 
-    def _edge_recon(self, rows, n_pairs, lib_gemm=False):
-        """``edge_recon_fc`` (``model/autoencoder.py:75-78``) on the pairs (row i, row n_pairs + i) of
-        ``rows``, with the weight gradients of its two linear layers on the streaming dW kernel (a
-        [rows, features] reduction over ~20k rows that the BLAS heuristics serve badly) and, with
-        ``lib_gemm``, the first layer's forward and row-gradient products on the projection kernels."""
+    def _edge_recon(self, pairs):
+        """``edge_recon_fc`` (``model/autoencoder.py:75-78``) with tensor operations, the weight gradients of its
+        two linear layers on the streaming dW kernel (a [rows, features] reduction over ~20k rows that the BLAS
+        heuristics serve badly)."""
         fc1, act, fc2, sig = self.edge_recon_fc
-        h = act(_PairLinearFn.apply(rows, n_pairs, fc1.weight, fc1.bias, lib_gemm))
+        h = act(_LinearFn.apply(pairs, fc1.weight, fc1.bias))
         return sig(_LinearFn.apply(h, fc2.weight, fc2.bias))
 
     def compute_loss(self, g: Graph, perm=None, pos_idx=None, neg_pairs=None, drop_masks=None, return_parts=False,
@@ -352,7 +306,9 @@ class GMAEModel(nn.Module):
         pos = (src[pos_idx], dst[pos_idx])
         neg = (neg_pairs[0].to(g.device), neg_pairs[1].to(g.device))
         n_pairs = len(pos[0]) + len(neg[0])
-        sample_idx = torch.cat([pos[0], neg[0], pos[1], neg[1]])
+        # (src_0, dst_0, src_1, dst_1, ...): the gathered rows, viewed as [n_pairs, 2 * width], ARE the pair matrix
+        # torch.cat([h[src], h[dst]], dim=-1) of autoencoder.py:257-258 -- no second copy of it is made
+        sample_idx = torch.cat([pos[0], neg[0], pos[1], neg[1]]).view(2, n_pairs).t().reshape(-1)
 
         cfg = self._fused_cfg(use_g, drop_masks, drop_seeds) if fused else None
         if cfg is not None:
@@ -394,9 +350,10 @@ class GMAEModel(nn.Module):
             loss_sce = sce_loss_masked(recon_p, x_target, mask_nodes, self._alpha_l, n_dim=n_dim)
         loss = loss_sce
         # autoencoder.py:257-266: sampled edge reconstruction
-        loss_bce = self._edge_recon_loss(samples, len(pos[0]), len(neg[0]), neg_valid)
+        pairs = samples.view(n_pairs, -1)
+        loss_bce = self._edge_recon_loss(pairs, len(pos[0]), len(neg[0]), neg_valid)
         if loss_bce is None:
-            y_pred = self._edge_recon(samples, n_pairs, lib_gemm=samples.is_cuda).squeeze(-1)
+            y_pred = self._edge_recon(pairs).squeeze(-1)
             y = torch.cat([torch.ones(len(pos[0]), device=g.device), torch.zeros(len(neg[0]), device=g.device)])
             if neg_valid is None:
                 loss_bce = self.recon_loss(y_pred, y)

@@ -505,7 +505,7 @@ def test_edge_reconstruction_loss_tail_equals_tensor_path(cuda, hidden, n_pos, n
     layers = 2
     m = GMAEModel(8, 4, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(cuda)
     P = n_pos + n_neg
-    rows = torch.randn(2 * P, hidden * layers).to(cuda).requires_grad_(True)
+    rows = torch.randn(P, 2 * hidden * layers).to(cuda).requires_grad_(True)   # the pair matrix [h[src] | h[dst]]
     valid = (torch.rand(n_neg) > 0.3).to(cuda) if weighted else None
     with torch.no_grad():                      # two pairs far into saturation in float32 and float64 alike
         m.edge_recon_fc[0].bias.normal_()      # (zero-initialised by the model; the tail adds it on the fly)
@@ -519,7 +519,7 @@ def test_edge_reconstruction_loss_tail_equals_tensor_path(cuda, hidden, n_pos, n
     # float64 evaluation of the reference's statements (model/autoencoder.py:257-266)
     ref = copy.deepcopy(m.edge_recon_fc).double().cpu()
     r64 = rows.detach().double().cpu().requires_grad_(True)
-    y_pred = ref(torch.cat([r64[:P], r64[P:]], dim=-1)).squeeze(-1)
+    y_pred = ref(r64).squeeze(-1)
     y = torch.cat([torch.ones(n_pos), torch.zeros(n_neg)]).double()
     if weighted:
         w = torch.cat([torch.ones(n_pos), valid.cpu().double()])
