@@ -19,6 +19,7 @@ from typing import Optional
 import torch
 
 from .. import _lib
+from ..utils.loaddata import _one_hot_float
 from ..utils.utils import sample_range
 
 
@@ -101,7 +102,7 @@ class CapturedTrainStep:
         """``inputs``: keyword overrides of ``compute_loss`` (eager mode), or None for the static
         input buffers of the recorded step."""
         g, m = self.g, self.model
-        g.ndata["attr"] = torch.nn.functional.one_hot(self.ntype, self.n_dim).float()
+        g.ndata["attr"] = _one_hot_float(self.ntype, self.n_dim)
         if inputs is None:
             inputs = dict(perm=self.perm, pos_idx=self.pos, neg_pairs=(self.neg_u, self.neg_v),
                           neg_valid=self.neg_ok, drop_seeds=self.seeds)
