@@ -531,3 +531,38 @@ def test_edge_reconstruction_loss_tail_equals_tensor_path(cuda, hidden, n_pos, n
     assert rel_err(got["rows"].cpu().double(), r64.grad) < 5e-5
     for n, p in ref.named_parameters():
         assert rel_err(got[n].cpu().double(), p.grad) < 5e-5, n
+
+
+def test_fold_of_all_layers_in_one_launch_equals_the_per_layer_calls(cuda):
+    """magic_fold_fwd_multi / _bwd_multi against magic_fold_fwd / _bwd layer by layer, bit for bit: layers with and
+    without residual projection and bias, padded head widths, more layers than one launch holds (10 > 8), absent
+    incoming gradients."""
+    from magic_amd import _lib
+    gen = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=gen).to(cuda)   # noqa: E731
+    specs = [(4, 16, 16, 8, 5, True, True), (4, 16, 16, 64, 5, False, True), (1, 5, 8, 64, 5, False, True),
+             (4, 64, 64, 256, 20, False, False), (2, 3, 4, 7, 3, True, False)] * 2
+    layers = []
+    for H, D, Dp, F, e_dim, has_res, has_bias in specs:
+        layers.append((H, D, Dp, r(H * D, F), r(1, H, D), r(1, H, D), r(H * D, F) if has_res else None,
+                       r(H * D, e_dim), r(1, H, D), r(1, H, D) if has_bias else None))
+    multi = _lib.fold_fwd_multi(layers)
+    grads = []
+    for i, (lay, out) in enumerate(zip(layers, multi)):
+        H, D, Dp, w_fc, ah, at, w_res, w_efc, ae, bias = lay
+        single = _lib.fold_fwd(H, D, Dp, w_fc, ah, at, w_res, w_efc, ae, bias)
+        for a, b in zip(out, single):
+            assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), i
+        g = [r(*out[0].shape), r(*out[1].shape), r(*out[2].shape) if out[2] is not None else None]
+        if i == 3:
+            g[1] = None          # no gradient reached the edge-score table
+        if i == 6:
+            g[0] = None          # ... or the augmented weight
+        grads.append(tuple(g))
+    back = _lib.fold_bwd_multi(layers, grads)
+    for i, (lay, g, out) in enumerate(zip(layers, grads, back)):
+        H, D, Dp, w_fc, ah, at, w_res, w_efc, ae, bias = lay
+        single = _lib.fold_bwd(H, D, Dp, w_fc, ah, at, w_efc, ae, g[0], g[1], g[2], w_res is not None, bias is not None)
+        assert len(out) == len(single) == 7
+        for a, b in zip(out, single):
+            assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), i
