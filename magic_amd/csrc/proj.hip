@@ -20,7 +20,8 @@
 
 namespace magic {
 int proj_rows_try(const ProjArgs &a, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream);
-int proj_gemm_try(const ProjArgs &a, void *planes_ws, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream);
+int proj_gemm_try(const ProjArgs &a, void *planes_ws, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream,
+                  bool relaxed = false);
 size_t proj_gemm_workspace_bytes(int F, int M);
 }
 
@@ -466,6 +467,8 @@ int dispatch(const ProjArgs &a0, void *gemm_ws, hipStream_t stream) {
     if (st_gemm != MAGIC_ERR_UNSUPPORTED) return st_gemm;
     const int st_rows = magic::proj_rows_try(a, nullptr, nullptr, false, stream);
     if (st_rows != MAGIC_ERR_UNSUPPORTED) return st_rows;
+    const int st_relaxed = magic::proj_gemm_try(a, gemm_ws, nullptr, nullptr, false, stream, true);
+    if (st_relaxed != MAGIC_ERR_UNSUPPORTED) return st_relaxed;
     const int tiles = (a.M + 31) / 32;
     if (tiles <= 10) {
         a.col0 = 0;

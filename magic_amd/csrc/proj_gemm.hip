@@ -273,13 +273,18 @@ template <bool EP> int launch(const ProjArgs &a, const GemmPlan &p, hipStream_t 
 
 bool gemm_shape(int F, int M) { return F >= 96 && M >= 128; }
 
+// Shapes the row-owner kernel cannot hold (its LDS-resident weight outgrows a CU: a long K against 64 outputs, or
+// many outputs from a short K) still run faster here, with part of the 128-column block idle, than on the
+// LDS-staged fallback; they are offered to this kernel after the row-owner one has declined.
+bool gemm_shape_relaxed(int F, int M) { return gemm_shape(F, M) || (F >= 256 && M >= 64) || (F >= 64 && M >= 256); }
+
 }  // namespace
 
 namespace magic {
 
 // bytes of workspace the block-tiled kernel needs for the split weight (0: shape not served)
 size_t proj_gemm_workspace_bytes(int F, int M) {
-    if (!gemm_shape(F, M)) return 0;
+    if (!gemm_shape_relaxed(F, M)) return 0;
     const size_t cbs = (M + GBN - 1) / GBN, nk = (F + GBK - 1) / GBK;
     return align_up(cbs * nk * TILE_ELEMS * 2);
 }
@@ -287,9 +292,12 @@ size_t proj_gemm_workspace_bytes(int F, int M) {
 // Runs the projection on the block-tiled kernel when it is a GEMM (wide K and M), the operand
 // alignment allows it and `planes_ws` (proj_gemm_workspace_bytes) is given; MAGIC_ERR_UNSUPPORTED
 // otherwise.  `n_part` / `n_win` describe the partial sums an epilogue launch writes:
-// part_col [n_part, C], part_prelu [n_win, n_part].
-int proj_gemm_try(const ProjArgs &a, void *planes_ws, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream) {
-    if (a.n <= 0 || !gemm_shape(a.F, a.M) || a.col0 != 0) return MAGIC_ERR_UNSUPPORTED;
+// part_col [n_part, C], part_prelu [n_win, n_part].  `relaxed`: also take the shapes of gemm_shape_relaxed
+// (launches without an epilogue only).
+int proj_gemm_try(const ProjArgs &a, void *planes_ws, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream,
+                  bool relaxed) {
+    if (a.n <= 0 || a.col0 != 0) return MAGIC_ERR_UNSUPPORTED;
+    if (!(relaxed && !has_epilogue(a) ? gemm_shape_relaxed(a.F, a.M) : gemm_shape(a.F, a.M))) return MAGIC_ERR_UNSUPPORTED;
     if ((a.F & 3) || !aligned16(a.x, a.ld_x)) return MAGIC_ERR_UNSUPPORTED;
     if (a.x_mask && ((uintptr_t)a.x_mask & 3)) return MAGIC_ERR_UNSUPPORTED;
     const bool ep = has_epilogue(a);

@@ -35,6 +35,9 @@ def _bound(a, b):
     (31, 11, 64, 8, 64, False, False),      # fewer rows than one tile
     (100, 13, 16, 8, 16, True, False),
     (64, 1024, 256, 0, 0, False, False),    # wide-layer GEMM kernel
+    (2250, 384, 64, 0, 0, False, False),    # edge-reconstruction head, 64-wide models: long K against 64 outputs
+    (1301, 2048, 256, 0, 0, False, False),  # ... 256-wide models
+    (700, 320, 64, 0, 0, True, False),
 ])
 def test_proj_fwd_against_float64(cuda, n, f, c, ns, rc, mask, strided):
     gen = torch.Generator(device=cuda).manual_seed(n * 7 + f)
@@ -67,6 +70,9 @@ def test_proj_fwd_against_float64(cuda, n, f, c, ns, rc, mask, strided):
     (130, 264, 256, True),     # 256-wide model: wide-layer GEMM kernel with the fused epilogue
     (130, 136, 5, False),      # layer-0 input gradient (narrow output)
     (77, 256, 1024, False),    # wide-layer GEMM kernel
+    (2250, 64, 384, False),    # edge-reconstruction head, 64-wide models: many outputs from a short K
+    (1301, 256, 2048, False),  # ... 256-wide models
+    (333, 72, 260, False),
 ])
 def test_proj_bwd_input_against_float64(cuda, n, k, f, full):
     gen = torch.Generator(device=cuda).manual_seed(n + k + f)
@@ -107,6 +113,7 @@ def test_proj_bwd_input_against_float64(cuda, n, k, f, full):
     (5000, 72, 64, True), (5000, 64, 192, False), (3001, 18, 64, True), (2000, 136, 5, True),
     (1500, 264, 256, True), (999, 136, 10, False), (40, 72, 64, False),
     (1500, 256, 1024, False), (901, 256, 384, True), (77, 128, 128, True),   # block-tiled kernel of the wide layers
+    (2250, 64, 384, False), (1301, 256, 2048, False),                        # edge-reconstruction head
 ])
 def test_proj_bwd_weight_against_float64(cuda, n, m_, f, mask):
     gen = torch.Generator(device=cuda).manual_seed(n + m_ + f)
