@@ -81,8 +81,7 @@ class _FoldAllFn(torch.autograd.Function):
         c = lambda t: None if t is None else t.contiguous()  # noqa: E731
         layers = [tuple(d) + tuple(map(c, tensors[7 * i:7 * i + 7])) for i, d in enumerate(dims)]
         outs = _lib.fold_fwd_multi(layers)
-        ctx.layers = [(H, D, Dp, None, None, None, w_res is not None, None, None, bias is not None)
-                      for (H, D, Dp, _w, _a, _b, w_res, _e, _f, bias) in layers]
+        ctx.dims = [(lay[0], lay[1], lay[2], lay[6] is not None, lay[9] is not None) for lay in layers]
         ctx.save_for_backward(*[t for lay in layers for t in (lay[3], lay[4], lay[5], lay[7], lay[8])])
         ctx.set_materialize_grads(False)
         return tuple(t for out in outs for t in out)
@@ -92,7 +91,7 @@ class _FoldAllFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         c = lambda t: None if t is None else t.contiguous()  # noqa: E731
         layers = []
-        for i, (H, D, Dp, _1, _2, _3, has_res, _4, _5, has_bias) in enumerate(ctx.layers):
+        for i, (H, D, Dp, has_res, has_bias) in enumerate(ctx.dims):
             w_fc, attn_h, attn_t, w_efc, attn_e = saved[5 * i:5 * i + 5]
             # (the residual weight / bias themselves are not read by the adjoint: only whether they exist)
             layers.append((H, D, Dp, w_fc, attn_h, attn_t, w_fc if has_res else None, w_efc, attn_e,
