@@ -37,21 +37,37 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// CAP = compile-time bound of n_dim: every per-column loop is fully unrolled, the row values and the
+// target-gradient partial sums live in registers, and the 2 CAP loads of a row are issued together
+// (clamped addresses, values beyond n_dim zeroed: fmaf(0, 0, s) == s keeps the sums bit-identical
+// for every CAP).
+template <int CAP>
 __global__ __launch_bounds__(256) void k_sce(SceArgs a) {
     __shared__ float red[4];
     float lsum = 0.f;
-    float dts[kMaxDim];  // only the first n_dim entries are live when d_trow is requested
+    float dts[CAP];
     const bool want_dt = a.d_trow != nullptr;
-    if (want_dt)
-        for (int j = 0; j < a.n_dim; ++j) dts[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CAP; ++j) dts[j] = 0.f;
     const float inv_m = 1.f / (float)a.n_mask;
+    const int nd = a.n_dim;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_mask; i += (int64_t)a.grid * 256) {
         const int64_t row = a.mask[i];
         const float *xr = a.x + row * a.ld_x;
         const float *tr = a.ld_t > 0 ? a.t + row * a.ld_t : a.t;
+        float xs[CAP], ts[CAP];
+#pragma unroll
+        for (int j = 0; j < CAP; ++j) {
+            const int jj = j < nd ? j : 0;
+            xs[j] = xr[jj];
+            ts[j] = tr[jj];
+        }
         float xx = 0.f, tt = 0.f, xt = 0.f;
-        for (int j = 0; j < a.n_dim; ++j) {
-            float xv = xr[j], tv = tr[j];
+#pragma unroll
+        for (int j = 0; j < CAP; ++j) {
+            const float xv = j < nd ? xs[j] : 0.f, tv = j < nd ? ts[j] : 0.f;
+            xs[j] = xv;
+            ts[j] = tv;
             xx = fmaf(xv, xv, xx);
             tt = fmaf(tv, tv, tt);
             xt = fmaf(xv, tv, xt);
@@ -79,10 +95,11 @@ __global__ __launch_bounds__(256) void k_sce(SceArgs a) {
         // d c / d x = (t^ - (x^.t^) x^) / |x|   if |x| >= eps (clamp passes), else t^ / eps
         float *dxr = a.d_x + row * a.ld_x;
         const bool xpass = nx >= kEps, tpass = nt >= kEps;
-        for (int j = 0; j < a.n_dim; ++j) {
-            float xh = xr[j] / dx, th = tr[j] / dt;
+#pragma unroll
+        for (int j = 0; j < CAP; ++j) {
+            float xh = xs[j] / dx, th = ts[j] / dt;
             float gx = xpass ? (th - c * xh) / dx : th / dx;
-            dxr[j] = gc * gx;
+            if (j < nd) dxr[j] = gc * gx;
             if (want_dt) {
                 float gt = tpass ? (xh - c * th) / dt : xh / dt;
                 dts[j] += gc * gt;
@@ -92,9 +109,12 @@ __global__ __launch_bounds__(256) void k_sce(SceArgs a) {
     float bl = block_sum(lsum, red);
     if (threadIdx.x == 0) a.ws_loss[blockIdx.x] = bl;
     if (want_dt) {
-        for (int j = 0; j < a.n_dim; ++j) {
-            float v = block_sum(dts[j], red);
-            if (threadIdx.x == 0) a.ws_dt[(int64_t)blockIdx.x * a.n_dim + j] = v;
+#pragma unroll
+        for (int j = 0; j < CAP; ++j) {
+            if (j < nd) {  // uniform over the block
+                float v = block_sum(dts[j], red);
+                if (threadIdx.x == 0) a.ws_dt[(int64_t)blockIdx.x * nd + j] = v;
+            }
         }
     }
 }
@@ -186,7 +206,13 @@ int magic_sce_fwd_bwd(int64_t n_rows, int32_t n_dim, int64_t n_mask, const int64
     a.ws_dt = ar.take<float>((size_t)a.grid * n_dim);
     if (!ar.ok() || !a.ws_loss || !a.ws_dt) return MAGIC_ERR_WORKSPACE;
     if (hipMemsetAsync(d_x, 0, sizeof(float) * (size_t)n_rows * ld_x, stream) != hipSuccess) return MAGIC_ERR_RUNTIME;
-    MAGIC_LAUNCH("sce_fwd_bwd", k_sce, a.grid, 256, 0, stream, a);
+    if (n_dim <= 8) {
+        MAGIC_LAUNCH("sce_fwd_bwd", k_sce<8>, a.grid, 256, 0, stream, a);
+    } else if (n_dim <= 16) {
+        MAGIC_LAUNCH("sce_fwd_bwd", k_sce<16>, a.grid, 256, 0, stream, a);
+    } else {
+        MAGIC_LAUNCH("sce_fwd_bwd", k_sce<kMaxDim>, a.grid, 256, 0, stream, a);
+    }
     MAGIC_LAUNCH("sce_final", k_sce_final, 1, 256, 0, stream, a);
     return magic::launch_status();
 }
@@ -220,7 +246,10 @@ int magic_sce_fwd_bwd_static(int64_t n_rows, int32_t n_dim, int64_t n_mask, cons
     a.ws_dt = base + kStaticGrid;     // [grid, n_dim]   nothing has to start at zero
     if (hipMemsetAsync(d_x, 0, sizeof(float) * (size_t)n_rows * ld_x, stream) != hipSuccess) return MAGIC_ERR_RUNTIME;
     // plain launches: the timing brackets of MAGIC_LAUNCH create events
-    hipLaunchKernelGGL(k_sce, dim3(a.grid), dim3(256), 0, stream, a);
+    if (n_dim <= 8)
+        hipLaunchKernelGGL(k_sce<8>, dim3(a.grid), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_sce<16>, dim3(a.grid), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(k_sce_final, dim3(1), dim3(256), 0, stream, a);
     return magic::launch_status();
 }
