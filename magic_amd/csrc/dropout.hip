@@ -11,8 +11,10 @@ struct Philox {
 };
 
 __device__ __forceinline__ void philox_round(Philox &p) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, p.c[0]), lo0 = 0xD2511F53u * p.c[0];
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, p.c[2]), lo1 = 0xCD9E8D57u * p.c[2];
+    // one 32x32->64 multiply per product (v_mad_u64_u32) instead of a high and a low multiply
+    const uint64_t m0 = (uint64_t)0xD2511F53u * p.c[0], m1 = (uint64_t)0xCD9E8D57u * p.c[2];
+    const uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0;
+    const uint32_t hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
     const uint32_t n0 = hi1 ^ p.c[1] ^ p.k[0], n2 = hi0 ^ p.c[3] ^ p.k[1];
     p.c[0] = n0, p.c[1] = lo1, p.c[2] = n2, p.c[3] = lo0;
     p.k[0] += 0x9E3779B9u, p.k[1] += 0xBB67AE85u;
