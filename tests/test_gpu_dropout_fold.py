@@ -67,7 +67,7 @@ def test_fold_matches_torch(cuda, H, D, Dp, F, e_dim, res, bias):
         assert torch.allclose(gm, gr, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("w", [192, 1024, 1100, 10, 514])   # element-wise form below 512 columns or unaligned, float4 form: four slabs, two passes
+@pytest.mark.parametrize("w", [192, 64, 384, 1024, 1100, 10, 514])   # element-wise form below 512 columns or unaligned, float4 form: four slabs, two passes
 def test_rows_scatter_add_with_repeats(cuda, w):
     from magic_amd import _lib
     g = torch.Generator().manual_seed(11)
