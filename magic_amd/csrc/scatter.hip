@@ -79,7 +79,25 @@ __global__ __launch_bounds__(256) void k_scatter_add4(int n, int width, const in
             on[q] = c0 + 256 * q < width;
             if (on[q]) acc[q] = *reinterpret_cast<const float4 *>(drow + c0 + 256 * q);
         }
-        for (int j = i; j < end; ++j) {
+        int j = i;
+        for (; j + 4 <= end; j += 4) {  // long runs (hub rows): four rows in flight, added in position order
+            const float *srow[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) srow[u] = src + (int64_t)pos[j + u] * ld_src + c0;
+            float4 v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (on[q]) v[u][q] = *reinterpret_cast<const float4 *>(srow[u] + 256 * q);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (on[q])
+                        acc[q].x += v[u][q].x, acc[q].y += v[u][q].y, acc[q].z += v[u][q].z, acc[q].w += v[u][q].w;
+        }
+        for (; j < end; ++j) {
             const float *srow = src + (int64_t)pos[j] * ld_src + c0;
             float4 v[4];
 #pragma unroll
