@@ -270,7 +270,8 @@ def test_knn_unsplit_rounds_and_split_tail_agree(cuda):
     assert np.array_equal(idx.cpu().numpy()[pick][clear], wi[clear])
 
 
-@pytest.mark.parametrize("n_dim,alpha,single", [(5, 3, False), (11, 3, True), (8, 2, False), (8, 1.5, True)])
+@pytest.mark.parametrize("n_dim,alpha,single", [(5, 3, False), (11, 3, True), (8, 2, False), (8, 1.5, True),
+                                                 (1, 3, True), (16, 3, False), (17, 3, True), (40, 2, False), (64, 3, True)])
 def test_sce_kernel(cuda, n_dim, alpha, single):
     from magic_amd.model.loss_func import sce_loss_masked
     torch.manual_seed(0)
