@@ -74,6 +74,7 @@ def test_rows_scatter_add_with_repeats(cuda, w):
     n, s = 500, 3000
     idx = torch.randint(0, n, (s,), generator=g)
     idx[:40] = 7                                          # a long run of one row
+    idx[100:330:1] = 11                                   # a hub row: a run longer than three 64-position scan steps
     src = torch.randn(s, w, generator=g)
     base = torch.randn(n, w + 8, generator=g)[:, :w]      # strided destination rows
     want = base.double().clone().index_add_(0, idx, src.double())
