@@ -50,24 +50,35 @@ def parse():
     p.add_argument("--knn-steps", type=int, default=2)
     p.add_argument("--no-knn", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-configs", action="store_true", help="skip the small side configurations (c1, c3)")
+    p.add_argument("--rows-file", default=None, help="where the per-kernel tables go (default: gpurun_out/ or here)")
     p.add_argument("--dry-run", action="store_true",
                    help="launch plumbing only: no GPU work, rank 0 prints n_gpus and the timing of a no-op step")
     return p.parse_args()
 
 
+# MAGIC_BENCH_FORCE_DIST=1 makes a one-rank run take every branch of the multi-rank run (RCCL process group,
+# barriers, gradient exchange, sharded KNN): the distributed code path on a one-GPU machine.
+FORCE_DIST = os.environ.get("MAGIC_BENCH_FORCE_DIST") == "1"
+
+
+def multi(world):
+    return world > 1 or FORCE_DIST
+
+
 def timed(fn, steps, world):
     """barrier + synchronize on both sides, max over ranks (seconds for `steps` calls)."""
-    if world > 1:
+    if multi(world):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         fn(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi(world):
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi(world):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -121,17 +132,6 @@ def sweep_bytes(kind, N, E_seg, E_all, H, C, res):
     raise ValueError(kind)
 
 
-def gather_ceiling_gbs(table_bytes):
-    """Measured chip-wide rate of uniformly random row gathers served from the caches
-    (MI355X micro-architecture guide, 'Indexed rows: gather into LDS'): 8.6 TB/s from a 38 MB
-    table, 7.4-7.9 TB/s from a 151 MB one, 6.0-6.1 TB/s from HBM."""
-    if table_bytes <= 64e6:
-        return 8600.0
-    if table_bytes <= CACHE_BYTES:
-        return 7900.0
-    return 6100.0
-
-
 def _stage_collectives_through_host():
     """Rehearsal mode only: gloo on device tensors of two ranks sharing one GPU does not progress
     here, so the collectives this file and the package use take a host copy, exchange it, copy back."""
@@ -159,45 +159,70 @@ def _stage_collectives_through_host():
     dist.all_to_all_single = all_to_all_single
 
 
-def dense_work(n, n_dim, hidden, layers, n_pairs):
-    """Algorithmic flops (2 per multiply-add) and HBM bytes (fp32 operands and results once, epilogue
-    operands not counted) of one step's projection launches, per kernel name."""
-    from magic_amd.model.gat import _pad_head_dim
-    H, C, L = 4, hidden, layers
-    dp = _pad_head_dim(n_dim)
-    w = {k: [0.0, 0.0] for k in ("proj_fwd_mfma_f32", "proj_bwd_input_mfma_f32", "proj_bwd_weight_mfma_f32")}
+def dense_launch(name, n, hidden, layers, n_pairs):
+    """Algorithmic flops (2 per multiply-add) and HBM bytes (fp32 operands and results once, epilogue operands
+    not counted) of ONE projection launch, from its profile name ``proj_fwd<K,M>`` / ``proj_bwd_input<K,M>`` /
+    ``proj_bwd_weight<M,F>``: a ``[rows, K] x [K, M]`` product.  The launches of the edge-reconstruction head are
+    the ones with the pair matrix's width (2 x layers x hidden) as one dimension: their row count is the number of
+    sampled pairs, every other launch runs over the N nodes."""
+    base, _, rest = name.partition("<")
+    if base not in ("proj_fwd", "proj_bwd_input", "proj_bwd_weight") or not rest:
+        return None
+    a, b = (int(v) for v in rest.rstrip(">").split(","))
+    rows = n_pairs if 2 * layers * hidden in (a, b) else n
+    return 2.0 * rows * a * b, 4.0 * rows * (a + b), rows
 
-    def add(name, rows, k, m):
-        w[name][0] += 2.0 * rows * k * m
-        w[name][1] += 4.0 * rows * (k + m)
-    for l in range(L):
-        f = n_dim if l == 0 else C
-        m = C + 2 * H + (C if f != C else 0)       # hs | eh, et | linear residual
-        add("proj_fwd_mfma_f32", n, f, m)
-        add("proj_bwd_weight_mfma_f32", n, 2 * f if l == 0 else f, m)  # layer 0 carries the mask-token indicator columns
-        if l > 0:
-            add("proj_bwd_input_mfma_f32", n, m, f)
-    add("proj_fwd_mfma_f32", n, L * C, C)          # encoder_to_decoder
-    add("proj_fwd_mfma_f32", n, C, dp + 2)         # decoder
-    add("proj_bwd_input_mfma_f32", n, C, L * C)
-    add("proj_bwd_input_mfma_f32", n, dp + 2, C)
-    add("proj_bwd_weight_mfma_f32", n, L * C, C)
-    add("proj_bwd_weight_mfma_f32", n, C, dp + 2)
-    add("proj_bwd_weight_mfma_f32", n_pairs, 2 * L * C, C)   # edge-reconstruction MLP
-    add("proj_bwd_weight_mfma_f32", n_pairs, C, 1)
-    return w
+
+def step_algorithmic(n, e, n_dim, hidden, layers, heads=4):
+    """Algorithmic HBM bytes and dense flops of one whole fwd+bwd step (fp32 values, int32 ids, every tensor moved
+    once per logical use): per GAT layer with input width F, H heads, C = H x D outputs
+      edge phase  fwd E(8 + 8H + 4C) + N(4 + 4H + 4C),  bwd E(20 + 16H + 8C) + N(8 + 8H + 8C)
+      node phase  fwd 4N(F + C + 2H),                   bwd 4N(F + 2C + 2H)
+    over the encoder layers and the decoder layer (H = 1, C = n_dim), plus encoder_to_decoder 8N(hL + h), the
+    gather of the sampled pairs 16T x 2hL (T = min(10000, N)) and the SCE loss 16 floor(N/2) n_dim;
+    flops 6NFC per layer + 6N hL h + 6 (2T) (2hL) h."""
+    t = min(10000, n)
+    by = fl = 0.0
+    lay = [(n_dim if l == 0 else hidden, heads, hidden) for l in range(layers)] + [(hidden, 1, n_dim)]
+    for f, h, c in lay:
+        by += e * (8 + 8 * h + 4 * c) + n * (4 + 4 * h + 4 * c) + e * (20 + 16 * h + 8 * c) + n * (8 + 8 * h + 8 * c)
+        by += 4 * n * (f + c + 2 * h) + 4 * n * (f + 2 * c + 2 * h)
+        fl += 6.0 * n * f * c
+    hl = hidden * layers
+    by += 8 * n * (hl + hidden) + 16 * t * 2 * hl + 16 * (n // 2) * n_dim
+    fl += 6.0 * n * hl * hidden + 6.0 * 2 * t * 2 * hl * hidden
+    return by, fl
+
+
+L2_GATHER_PEAK_GBS = 16800.0   # rows re-gathered from an XCD's L2: 16.8-18.8 TB/s chip-wide (micro-architecture guide)
+
+
+def classify_sweep(per_use, compulsory, gathered, table, traffic, sec):
+    """Roofline fields of one sparse-sweep launch.  ``achieved`` is always the algorithmic (per-use) byte count
+    over the launch time.  The bound follows the fabric counters: when the measured traffic is at least ~0.9 of
+    the per-use bytes the gathers are NOT served on-die and the launch is priced against the 8 TB/s HBM peak;
+    when the fabric moves clearly less than the per-use count (rows re-read from L2 / Infinity Cache) the
+    per-use rate is priced against the guide's L2 gather rate instead, so that no fraction exceeds 1."""
+    rate = per_use / sec / 1e9
+    ratio = traffic / per_use if traffic else None
+    on_die = gathered > 0 and ((ratio is not None and ratio < 0.9) or (ratio is None and rate > HBM_PEAK_GBS))
+    peak = L2_GATHER_PEAK_GBS if on_die else HBM_PEAK_GBS
+    return {"bound": "l2-gather" if on_die else "hbm", "achieved": round(rate, 1), "peak": peak, "unit": "GB/s",
+            "frac": round(rate / peak, 4), "per_use_bytes_per_launch": int(per_use),
+            "compulsory_bytes_per_launch": int(compulsory),
+            "compulsory_frac_of_hbm_peak": round(compulsory / sec / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "traffic_over_per_use": round(ratio, 3) if ratio is not None else None,
+            "traffic_rate_gbs": round(traffic / sec / 1e9, 1) if traffic else None}
 
 
 def roofline_rows(prof, struct, workload, steps, n, n_dim, hidden, layers, n_pairs):
-    """One row per kernel template instance of the step, most expensive first.
+    """One row per kernel template instance / launch shape of the step, most expensive first.
 
-    HBM-bound sparse sweeps carry two byte counts per launch (``sweep_bytes``): ``per_use`` and
-    ``compulsory``.  ``achieved`` / ``frac`` are the compulsory bytes over the launch time against
-    the 8 TB/s HBM peak -- the share of the HBM roofline the launch really uses.  A sweep whose
-    gathered node table fits the Infinity Cache is labelled ``"gather-cache"``: its per-edge row
-    gathers are served on-die, so their rate (``gather.rate``) is compared with the measured
-    cache-resident gather ceiling instead.  ``traffic`` = fabric bytes per launch from the PMC
-    counters (``profiles/traffic.json``), ``wasted`` = traffic / compulsory."""
+    Sparse sweeps: ``achieved`` = per-use bytes (``sweep_bytes``: every tensor once per logical use, a gathered
+    row once per edge) over the average launch time, see ``classify_sweep`` for the bound.  ``traffic`` = fabric
+    bytes per launch from the PMC counters (``profiles/traffic.json``).  Projection launches are named by shape
+    and priced by ``dense_launch``: against the matrix ceiling of their arithmetic past its ridge, against HBM
+    below it."""
     from magic_amd.graph import LIGHT_MAX
     from magic_amd.model.gat import _pad_head_dim
     deg_in = (struct.in_ptr[1:] - struct.in_ptr[:-1]).long()
@@ -215,7 +240,6 @@ def roofline_rows(prof, struct, workload, steps, n, n_dim, hidden, layers, n_pai
                                   ("gat_bwd_src_light", "bwd_src", e_out), ("gat_bwd_dst_light", "bwd_dst", e_in),
                                   ("gat_bwd_deh_light", "bwd_deh", e_out)):
             sparse.setdefault(base + t, []).append(sweep_bytes(kind, n, e_seg, E, H, C, r))
-    dense = dense_work(n, n_dim, hidden, layers, n_pairs)
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         traffic_tab = json.load(open(tpath)).get(workload, {}) if os.path.exists(tpath) else {}
@@ -229,37 +253,21 @@ def roofline_rows(prof, struct, workload, steps, n, n_dim, hidden, layers, n_pai
         sec = tot_ms / cnt * 1e-3               # average launch duration
         row = {"kernel": name, "avg_launch_us": round(sec * 1e6, 2), "launches_per_step": per_step,
                "ms_per_step": round(tot_ms / steps, 4)}
+        dense = dense_launch(name, n, hidden, layers, n_pairs)
         if name in sparse:
             per_use, comp, gath, table = (sum(x[i] for x in sparse[name]) / len(sparse[name]) for i in range(4))
-            traffic = traffic_tab.get(name)
-            cached = 0 < table <= CACHE_BYTES and gath > 0
-            row.update({"bound": "gather-cache" if cached else "hbm",
-                        "achieved": round(comp / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(comp / sec / 1e9 / HBM_PEAK_GBS, 4),
-                        "compulsory_bytes_per_launch": int(comp), "per_use_bytes_per_launch": int(per_use),
-                        "per_use_rate_gbs": round(per_use / sec / 1e9, 1),
-                        "traffic": traffic, "wasted": round(traffic / comp, 3) if traffic else None,
-                        # fabric bytes against the per-use count: < 1 when gathers hit the XCD's L2, > 1 when random
-                        # accesses move more than they use
-                        "traffic_over_per_use": round(traffic / per_use, 3) if traffic else None})
-            if gath > 0:
-                ceil = gather_ceiling_gbs(table)
-                row["gather"] = {"table_bytes": int(table), "gathered_bytes_per_launch": int(gath),
-                                 "rate_gbs": round(gath / sec / 1e9, 1), "ceiling_gbs": ceil,
-                                 "frac_of_ceiling": round(gath / sec / 1e9 / ceil, 4)}
-        elif name in dense:
-            fl, by = dense[name]
-            fl, by = fl / per_step, by / per_step
+            row.update(classify_sweep(per_use, comp, gath, table, traffic_tab.get(name), sec))
+        elif dense is not None:
+            fl, by, nrows = dense
             # The projections form every fp32 product from six bf16 matrix products (split operands), so their
             # matrix ceiling is the dense bf16 peak / 6; a launch is matrix-bound past the ridge of that ceiling.
             split_peak = BF16_MFMA_PEAK_TF / 6.0
+            row["rows"] = nrows
             if fl / by > split_peak * 1e3 / HBM_PEAK_GBS:
                 ach = fl / sec / 1e12
                 row.update({"bound": "mfma", "achieved": round(ach, 1), "peak": round(split_peak, 1), "unit": "TFLOP/s",
-                            "frac": round(ach / split_peak, 4), "algorithmic_flops_per_launch": int(fl),
-                            "arithmetic": "fp32-grade products as 6 bf16 MFMA products (peak = dense bf16 peak / 6); "
-                                          "the fp32 matrix instruction peaks at %.1f" % F32_MFMA_PEAK_TF,
-                            "traffic": None})
+                            "frac": round(ach / split_peak, 4), "frac_of_f32_mfma_peak": round(ach / F32_MFMA_PEAK_TF, 4),
+                            "algorithmic_flops_per_launch": int(fl), "traffic": traffic_tab.get(name)})
             else:
                 ach = by / sec / 1e9
                 row.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -271,10 +279,12 @@ def roofline_rows(prof, struct, workload, steps, n, n_dim, hidden, layers, n_pai
     return rows, kernels
 
 
-def gat_leg(args, workload, steps, warmup, world, rank, dev):
-    """Times `steps` training steps of `workload`; returns the numbers of the JSON line."""
+def gat_leg(args, workload, steps, warmup, world, rank, dev, detail=True):
+    """Times `steps` training steps of `workload`; returns the numbers of the JSON line.  ``detail=False``
+    (the small side configurations): eager and recorded step time only -- no per-kernel pass, no
+    end-to-end loop."""
     from magic_amd import _lib, synth
-    from magic_amd.model.autoencoder import GMAEModel, _negative_candidates
+    from magic_amd.model.autoencoder import GMAEModel, _negative_candidates, negative_candidate_count
     from magic_amd.model.step import CapturedTrainStep, make_adam
     from magic_amd.parallel import FlatGradAllReduce, broadcast_parameters
     from magic_amd.utils.utils import create_optimizer, set_random_seed
@@ -314,7 +324,7 @@ def gat_leg(args, workload, steps, warmup, world, rank, dev):
         assembly_ms = (time.perf_counter() - t0) / 3 * 1e3
         del g2
         n = g.num_nodes()
-        if world == 1:
+        if world == 1 and detail:
             # the reference's loop itself (model/train.py:18-48): per step transform_graph on the 12
             # graphs, batch, masking / sampling inside the model, backward, Adam -- nothing pre-generated
             from magic_amd.model.train import batch_level_train
@@ -349,7 +359,7 @@ def gat_leg(args, workload, steps, warmup, world, rank, dev):
     # The product's step harness: fresh one-hot node attributes, compute_loss forward, backward,
     # gradient all-reduce (N > 1), Adam.  The timed step is the eager one; the same step recorded as
     # a HIP graph and replayed is timed beside it (config.recorded_ms_per_step).
-    exchange = flat if world > 1 else None
+    exchange = flat if multi(world) else None
     eager = CapturedTrainStep(model, opt, g, n_dim, grad_exchange=exchange)
     cap = CapturedTrainStep(model, opt, g, n_dim, grad_exchange=exchange, capture=True, warmup=2)
 
@@ -369,12 +379,14 @@ def gat_leg(args, workload, steps, warmup, world, rank, dev):
     for i in range(4):                       # the harness's eager warm-up calls, its recording, a replay
         step_rec(i)
     eager_ms = timed(step_rec, steps, world) / steps * 1e3     # (reported as recorded_ms_per_step)
+    if not detail:
+        return {"ms_per_step": ms_per_step, "edges_per_s": edges_per_s, "eager_ms": eager_ms, "n": n, "e": E}
     # ---- per-kernel timing over a further timed region (HIP events on the launch stream)
     _lib.prof_reset()
     _lib.prof_enable(True)
     dt_prof = timed(step_eager, steps, world)
     _lib.prof_enable(False)
-    prof = _lib.prof_read(128)
+    prof = _lib.prof_read(160)
     _lib.prof_reset()
 
     roofline = None
@@ -382,15 +394,18 @@ def gat_leg(args, workload, steps, warmup, world, rank, dev):
     rows = []
     kernels = {}
     if rank == 0:
-        rows, kernels = roofline_rows(prof, g.structure, workload, steps, n, n_dim, hidden, layers, 2 * thr)
+        rows, kernels = roofline_rows(prof, g.structure, workload, steps, n, n_dim, hidden, layers,
+                                       thr + negative_candidate_count(thr))
         if rows:
             roofline = dict(rows[0], profiled_ms_per_step=round(dt_prof / steps * 1e3, 3))
             others = rows[1:4]
     desc = {"theia": "E3-THEIA-shaped full graph", "streamspot_batch": "StreamSpot batch-level training, batch of "
             "12 graphs"}.get(workload, workload)
+    adam_ms = sum(v["total_ms_per_step"] for k, v in kernels.items() if k.startswith("adam_"))
     return {"ms_per_step": ms_per_step, "edges_per_s": edges_per_s, "roofline": roofline, "roofline_next": others,
             "roofline_rows": rows, "kernels": kernels, "batch_assembly_ms": assembly_ms, "end_to_end_ms": e2e_ms,
-            "eager_ms": eager_ms,
+            "eager_ms": eager_ms, "adam_ms": adam_ms, "n": n, "e": E, "shape": (n_dim, e_dim, hidden, layers),
+            "kernel_sum_ms": sum(v["total_ms_per_step"] for v in kernels.values()),
             "workload": f"{desc} per GPU ({workload}): N={n} E={E} n_dim={n_dim} e_dim={e_dim} hidden={hidden} "
                         f"layers={layers}; one-hot attributes + compute_loss fwd + bwd + Adam, dropout on, mask perms "
                         "and sampled pairs pre-generated on the device",
@@ -462,7 +477,11 @@ def main():
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if FORCE_DIST:
+        os.environ["MAGIC_FORCE_COLLECTIVES"] = "1"
+        for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(key, val)
+    if multi(world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -476,14 +495,15 @@ def main():
     entity = None
     if world == 1 and not args.no_entity and args.workload != "theia":
         torch.cuda.empty_cache()
-        el = gat_leg(args, "theia", args.steps, args.warmup, world, rank, dev)
-        entity = {"metric": "masked-GAT fwd+bwd edges/sec", "value": round(el["edges_per_s"], 1), "unit": "edges/s",
-                  "ms_per_step": round(el["ms_per_step"], 4),
-                  "config": {"workload": el["workload"], "recorded_ms_per_step": round(el["eager_ms"], 4)},
-                  "north_star_target": True,
-                  "roofline": el["roofline"], "roofline_next": el["roofline_next"],
-                  "roofline_rows": el["roofline_rows"], "kernels": el["kernels"]}
+        entity = gat_leg(args, "theia", args.steps, args.warmup, world, rank, dev)
         torch.cuda.empty_cache()
+
+    # ---- the small configurations (single StreamSpot graph, Wget average / largest): step times only
+    configs = {}
+    if world == 1 and not args.no_configs and args.workload == "streamspot_batch":
+        for key, wl in (("c1", "streamspot"), ("c3_avg", "wget"), ("c3_max", "wget_max")):
+            configs[key] = gat_leg(args, wl, max(args.steps, 10), max(args.warmup, 3), world, rank, dev, detail=False)
+            torch.cuda.empty_cache()
 
     # ---- KNN leg
     knn = None
@@ -498,28 +518,93 @@ def main():
             knn["cpu_baseline"] = cpu_knn_baseline(args)
 
     if rank == 0:
-        out = {
-            "metric": "masked-GAT fwd+bwd edges/sec", "value": round(leg["edges_per_s"], 1), "unit": "edges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(leg["ms_per_step"], 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": leg["workload"],
-                       "parallelism": f"dp{world} (one batch per rank, flat-buffer gradient all-reduce)"
-                                      if world > 1 else "single GPU",
-                       "batch_assembly_ms": None if leg["batch_assembly_ms"] is None
-                       else round(leg["batch_assembly_ms"], 3),
-                       "recorded_ms_per_step": round(leg["eager_ms"], 4),
-                       "end_to_end_ms_per_step": None if leg["end_to_end_ms"] is None
-                       else round(leg["end_to_end_ms"], 3)},
-            "roofline": leg["roofline"], "roofline_next": leg["roofline_next"], "cpu_baseline": cpu_baseline,
-            # peers of the top-level leg: "entity_level" is the single-GPU target the north star names
-            # (E3-THEIA-shaped full graph); the top-level leg is the one that shards over GPUs
-            "north_star_target": "entity_level (single GPU) + knn; the top-level leg is the data-parallel one",
-            "entity_level": entity, "knn": knn, "roofline_rows": leg["roofline_rows"], "kernels": leg["kernels"],
-        }
-        print(json.dumps(out))
-    if world > 1:
+        rows_path = write_rows_file(args, leg, entity, knn)
+        print(json.dumps(compact_line(args, world, leg, entity, knn, configs, cpu_baseline, rows_path)))
+    if multi(world):
         dist.destroy_process_group()
+
+
+def write_rows_file(args, leg, entity, knn):
+    """Everything too long for the one-line result (one roofline row and one timing entry per kernel of every
+    leg) goes to a side file: ``--rows-file``, else ``gpurun_out/bench_rows.json`` when that directory exists,
+    else ``bench_rows.json`` beside this script."""
+    path = args.rows_file
+    if not path:
+        d = os.path.join(ROOT, "gpurun_out")
+        path = os.path.join(d if os.path.isdir(d) else ROOT, "bench_rows.json")
+    doc = {"note": "sparse sweeps: achieved = per-use bytes / average launch time; projections: every fp32-grade "
+                   "product is six bf16 MFMA products, matrix ceiling = dense bf16 peak / 6 = "
+                   f"{BF16_MFMA_PEAK_TF / 6:.1f} TFLOP/s (the fp32 matrix instruction peaks at {F32_MFMA_PEAK_TF})",
+           "top": {"workload": leg["workload"], "roofline_rows": leg["roofline_rows"], "kernels": leg["kernels"]}}
+    if entity:
+        doc["entity_level"] = {"workload": entity["workload"], "roofline_rows": entity["roofline_rows"],
+                               "kernels": entity["kernels"]}
+    if knn and "kernels" in knn:
+        doc["knn"] = {"workload": knn["config"]["workload"], "kernels": knn["kernels"], "roofline": knn.get("roofline")}
+    try:
+        with open(path, "w") as f:
+            json.dump(doc, f, indent=1)
+    except OSError:
+        return None
+    return os.path.relpath(path, ROOT)
+
+
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches_per_step")
+
+
+def _roof(r):
+    return None if not r else {k: r.get(k) for k in ROOF_KEYS}
+
+
+def _step_roof(leg):
+    """Whole-step figure beside the dominant kernel's: algorithmic bytes of the step at 8 TB/s over the step."""
+    by, fl = step_algorithmic(leg["n"], leg["e"], leg["shape"][0], leg["shape"][2], leg["shape"][3])
+    t_hbm = by / (HBM_PEAK_GBS * 1e9) * 1e3
+    return {"algorithmic_gb": round(by / 1e9, 2), "dense_gflop": round(fl / 1e9, 1),
+            "ms_at_hbm_peak": round(t_hbm, 3), "frac": round(t_hbm / leg["ms_per_step"], 4)}
+
+
+def compact_line(args, world, leg, entity, knn, configs, cpu_baseline, rows_path):
+    """The ONE result line (kept under 4 KB: the per-kernel tables live in the rows file)."""
+    def r4(x):
+        return None if x is None else round(x, 4)
+    out = {
+        "metric": "masked-GAT fwd+bwd edges/sec", "value": round(leg["edges_per_s"], 1), "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r4(leg["ms_per_step"]),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": leg["workload"],
+                   "parallelism": f"dp{world}: one batch per rank, one flat gradient all-reduce"
+                   if multi(world) else "single GPU",
+                   "batch_assembly_ms": r4(leg["batch_assembly_ms"]), "recorded_ms_per_step": r4(leg["eager_ms"]),
+                   "end_to_end_ms_per_step": r4(leg["end_to_end_ms"]), "adam_ms": r4(leg.get("adam_ms"))},
+        "roofline": _roof(leg["roofline"]), "step_roofline": _step_roof(leg) if leg.get("shape") else None,
+        "cpu_baseline": None if cpu_baseline is None else {k: cpu_baseline[k] for k in
+                                                           ("value", "unit", "cores", "kind", "sample")},
+    }
+    if entity:
+        out["entity_level"] = {"north_star_target": True, "value": round(entity["edges_per_s"], 1), "unit": "edges/s",
+                               "ms_per_step": r4(entity["ms_per_step"]), "recorded_ms_per_step": r4(entity["eager_ms"]),
+                               "adam_ms": r4(entity.get("adam_ms")),
+                               "workload": "E3-THEIA-shaped full graph N=%d E=%d hidden=%d layers=%d, same step" %
+                                           (entity["n"], entity["e"], entity["shape"][2], entity["shape"][3]),
+                               "roofline": _roof(entity["roofline"]), "step_roofline": _step_roof(entity)}
+    if knn:
+        k = {key: knn[key] for key in ("metric", "value", "unit", "ms_per_step", "dtype", "steps") if key in knn}
+        k["workload"] = knn["config"]["short"]
+        k["roofline"] = _roof(knn.get("roofline"))
+        for extra in ("cadets",):
+            if knn.get(extra):
+                k[extra] = knn[extra]
+        cb = knn.get("cpu_baseline")
+        k["cpu_baseline"] = None if cb is None else {x: cb[x] for x in ("value", "unit", "cores", "kind", "sample")}
+        out["knn"] = k
+    if configs:
+        out["configs"] = {key: {"n": c["n"], "e": c["e"], "ms_per_step": r4(c["ms_per_step"]),
+                                "recorded_ms_per_step": r4(c["eager_ms"]),
+                                "edges_per_s": round(c["e"] / min(c["ms_per_step"], c["eager_ms"]) * 1e3, 1)}
+                          for key, c in configs.items()}
+    out["rows_file"] = rows_path
+    return out
 
 
 def knn_leg(args, world, rank, dev):
@@ -554,8 +639,8 @@ def knn_leg(args, world, rank, dev):
     counts = [int(((sample >= min(r * per, nt)) & (sample < min((r + 1) * per, nt))).sum()) for r in range(world)]
 
     def step(_i):
-        xt, xq = standardise_device(train, query, sharded=world > 1)
-        if world > 1:
+        xt, xq = standardise_device(train, query, sharded=multi(world))
+        if multi(world):
             nn_ = ShardedNearestNeighbors(k, device=dev)
             nn_.fit(x_local=xt, offset=lo)
             # 50,000 x 64 floats in all; the ranks hold different numbers of the sampled rows
@@ -575,7 +660,9 @@ def knn_leg(args, world, rank, dev):
     _lib.prof_reset()
     res = {"metric": "KNN-score queries/sec", "value": round(nq * args.knn_steps / dt, 1), "unit": "queries/s",
            "ms_per_step": round(dt / args.knn_steps * 1e3, 3), "dtype": "f64", "steps": args.knn_steps,
-           "config": {"workload": f"E3-Trace-shaped outlier scoring: train {nt} x {d} f32 sharded over {world} rank(s), "
+           "config": {"short": f"E3-Trace-shaped scoring: train {nt}x{d} over {world} rank(s), {nq} test rows + "
+                               f"{n_sample}-row mean_distance search per step, k={k}",
+                      "workload": f"E3-Trace-shaped outlier scoring: train {nt} x {d} f32 sharded over {world} rank(s), "
                                   f"all {nq} test rows per step, k={k}; standardise + mean_distance search of "
                                   f"{n_sample} train rows + test search + row mean + score, all on the device"}}
     # dominant kernel: the matrix-core filter of the two-stage search (every query-train pair goes through it

@@ -26,6 +26,10 @@ struct ProfScope {
     }
 };
 
+// Raise a kernel's dynamic-LDS limit to at least `bytes` on the CURRENT device (the attribute is kept per
+// device, so the largest request is remembered per (kernel, device)).  Returns MAGIC_OK or MAGIC_ERR_RUNTIME.
+int ensure_dynamic_lds(const void *kernel, size_t bytes);
+
 inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MAGIC_OK : MAGIC_ERR_LAUNCH;

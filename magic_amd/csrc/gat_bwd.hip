@@ -760,13 +760,7 @@ int launch_table(BwdArgs &a, hipStream_t stream) {
         return MAGIC_OK;
     }
     const size_t sh = (size_t)a.e_dim * H * TBL_THREADS * sizeof(float);
-    static size_t attr_bytes = 0;
-    if (sh > 48 * 1024 && sh > attr_bytes) {
-        if (hipFuncSetAttribute((const void *)k_bwd_table_partial<H>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)sh) != hipSuccess)
-            return MAGIC_ERR_RUNTIME;
-        attr_bytes = sh;
-    }
+    if (magic::ensure_dynamic_lds((const void *)k_bwd_table_partial<H>, sh) != MAGIC_OK) return MAGIC_ERR_RUNTIME;
     MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_table_partial", H, LPH) : "gat_bwd_table_partial", (k_bwd_table_partial<H>), a.grid_table, TBL_THREADS, sh, stream, a);
     MAGIC_LAUNCH("gat_bwd_table_final", k_bwd_table_final, a.e_dim * H, 256, 0, stream, a, H);
     return MAGIC_OK;

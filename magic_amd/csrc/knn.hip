@@ -1035,13 +1035,7 @@ int magic_knn_topk(int64_t n_train, int64_t n_query, int32_t d, int32_t k, const
         const int kf = filter_kf(k);
         FilterWs w;
         if (!filter_workspace(ar, n_train, n_query, k, &w)) return MAGIC_ERR_WORKSPACE;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)k_knn_filter_bf16, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    80 * 1024) != hipSuccess)
-                return MAGIC_ERR_RUNTIME;
-            attr_set = true;
-        }
+        if (magic::ensure_dynamic_lds((const void *)k_knn_filter_bf16, 80 * 1024) != MAGIC_OK) return MAGIC_ERR_RUNTIME;
         if (hipMemsetAsync(w.tmax, 0, sizeof(unsigned long long), stream) != hipSuccess) return MAGIC_ERR_RUNTIME;
         MAGIC_LAUNCH("knn_tmax", k_tmax, magic::stride_grid(n_train, 256 * 16, 1024), 256, 0, stream, n_train, tnorm, w.tmax);
         // float32 accumulation of d products in 6 * d/16 matrix steps + the dropped cross products (2^-23 each)

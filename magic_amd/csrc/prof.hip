@@ -66,6 +66,21 @@ void prof_end(hipStream_t s) {
     g_open_a = nullptr;
 }
 
+int ensure_dynamic_lds(const void *kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return MAGIC_OK;  // within the default limit
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> granted;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MAGIC_ERR_RUNTIME;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t &have = granted[{kernel, dev}];
+    if (bytes <= have) return MAGIC_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return MAGIC_ERR_RUNTIME;
+    have = bytes;
+    return MAGIC_OK;
+}
+
 }  // namespace magic
 
 extern "C" {

@@ -381,12 +381,7 @@ int stream_grid(const ProjArgs &a, int nct, int kch, int mode) {
 
 template <int NCT, int KCH, int MODE> int launch_stream_mode(const ProjArgs &a, hipStream_t stream) {
     size_t sh = stream_lds(NCT, KCH, MODE);
-    static bool attr_set = false;
-    if (sh > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_proj_stream<NCT, KCH, MODE>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        attr_set = true;
-    }
+    if (magic::ensure_dynamic_lds((const void *)k_proj_stream<NCT, KCH, MODE>, sh) != MAGIC_OK) return MAGIC_ERR_RUNTIME;
     MAGIC_LAUNCH(a.name, (k_proj_stream<NCT, KCH, MODE>), stream_grid(a, NCT, KCH, MODE), 256, sh, stream, a);
     return magic::launch_status();
 }
@@ -414,11 +409,7 @@ bool has_stream(int nct, int kch) {
 template <int NCT, bool EP> int launch_block_ep(const ProjArgs &a, hipStream_t stream) {
     size_t sh = (size_t)(BM + NCT * 32) * LDS_LD * sizeof(float);
     unsigned grid = (unsigned)((a.n + BM - 1) / BM);
-    static bool attr_set = false;
-    if (sh > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_proj<NCT, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        attr_set = true;
-    }
+    if (magic::ensure_dynamic_lds((const void *)k_proj<NCT, EP>, sh) != MAGIC_OK) return MAGIC_ERR_RUNTIME;
     MAGIC_LAUNCH(a.name, (k_proj<NCT, EP>), grid, 256, sh, stream, a);
     return magic::launch_status();
 }
@@ -531,7 +522,7 @@ int magic_proj_fwd(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_scor
     a.w = w;
     a.w_rs = in_dim;
     a.w_cs = 1;
-    a.name = "proj_fwd_mfma_f32";
+    a.name = magic::prof_on() ? magic::prof_name("proj_fwd", in_dim, a.M) : "proj_fwd";
     a.hs = hs;
     a.ld_hs = ld_hs;
     a.score = score;
@@ -575,7 +566,7 @@ int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim, const f
     a.w = w;  // [k_dim, out_dim] row-major, read transposed
     a.w_rs = 1;
     a.w_cs = out_dim;
-    a.name = "proj_bwd_input_mfma_f32";
+    a.name = magic::prof_on() ? magic::prof_name("proj_bwd_input", k_dim, out_dim) : "proj_bwd_input";
     a.hs = dx;
     a.ld_hs = ld_dx;
     bool sums = false;

@@ -218,13 +218,9 @@ DwPlan plan_dw(int64_t n, int M, int F) {
 template <int MT, int FT> int run_dw(DwArgs &a, const DwPlan &p, hipStream_t stream) {
     constexpr int TILE = MT * FT * 16 * 64;
     size_t sh = (size_t)TILE * sizeof(float);
-    static bool attr_set = false;
-    if (sh > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_proj_dw<MT, FT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        attr_set = true;
-    }
+    if (magic::ensure_dynamic_lds((const void *)k_proj_dw<MT, FT>, sh) != MAGIC_OK) return MAGIC_ERR_RUNTIME;
     dim3 grid(p.n_strips, p.mg * p.fg);
-    MAGIC_LAUNCH("proj_bwd_weight_mfma_f32", (k_proj_dw<MT, FT>), grid, 256, sh, stream, a);
+    MAGIC_LAUNCH(magic::prof_on() ? magic::prof_name("proj_bwd_weight", a.M, a.F) : "proj_bwd_weight", (k_proj_dw<MT, FT>), grid, 256, sh, stream, a);
     dim3 rgrid(TILE / 32, p.mg * p.fg);
     MAGIC_LAUNCH("proj_bwd_weight_reduce", (k_proj_dw_reduce<MT, FT>), rgrid, 256, 0, stream, a);
     return magic::launch_status();
@@ -454,19 +450,13 @@ WidePlan plan_wide(int64_t n, int M, int F) {
 }
 
 int run_wide(DwArgs &a, const WidePlan &p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_proj_dw_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)WIDE_LDS) != hipSuccess)
-            return MAGIC_ERR_RUNTIME;
-        attr_set = true;
-    }
+    if (magic::ensure_dynamic_lds((const void *)k_proj_dw_wide, WIDE_LDS) != MAGIC_OK) return MAGIC_ERR_RUNTIME;
     WideArgs w;
     w.a = a;
     w.m_blocks = p.m_blocks, w.f_blocks = p.f_blocks, w.n_strips = p.n_strips;
     w.rows_per_strip = p.rows_per_strip;
     dim3 grid(p.n_strips, p.m_blocks * p.f_blocks);
-    MAGIC_LAUNCH("proj_bwd_weight_mfma_f32", k_proj_dw_wide, grid, 256, WIDE_LDS, stream, w);
+    MAGIC_LAUNCH(magic::prof_on() ? magic::prof_name("proj_bwd_weight", a.M, a.F) : "proj_bwd_weight", k_proj_dw_wide, grid, 256, WIDE_LDS, stream, w);
     dim3 rgrid(WT * WT / 256, p.m_blocks * p.f_blocks);
     MAGIC_LAUNCH("proj_bwd_weight_reduce", k_proj_dw_wide_reduce, rgrid, 256, 0, stream, w);
     return magic::launch_status();

@@ -260,13 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_proj_gemm(ProjArgs a, GemmPlan p) {
 }
 
 template <bool EP> int launch(const ProjArgs &a, const GemmPlan &p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_proj_gemm<EP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)GEMM_LDS) != hipSuccess)
-            return MAGIC_ERR_RUNTIME;
-        attr_set = true;
-    }
+    if (magic::ensure_dynamic_lds((const void *)k_proj_gemm<EP>, GEMM_LDS) != MAGIC_OK) return MAGIC_ERR_RUNTIME;
     MAGIC_LAUNCH(a.name, (k_proj_gemm<EP>), (unsigned)(p.per_xcd * 8), 256, GEMM_LDS, stream, a, p);
     return magic::launch_status();
 }

@@ -326,13 +326,7 @@ bool choose(const ProjArgs &a, int mw, Choice &c) {
 }
 
 template <int KQB, int NCG, bool EP> int launch(const ProjArgs &a, const Choice &c, hipStream_t stream) {
-    static size_t attr_bytes = 0;
-    if (c.lds > 48 * 1024 && c.lds > attr_bytes) {
-        if (hipFuncSetAttribute((const void *)k_proj_rows<KQB, NCG, EP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)c.lds) != hipSuccess)
-            return MAGIC_ERR_RUNTIME;
-        attr_bytes = c.lds;
-    }
+    if (magic::ensure_dynamic_lds((const void *)k_proj_rows<KQB, NCG, EP>, c.lds) != MAGIC_OK) return MAGIC_ERR_RUNTIME;
     MAGIC_LAUNCH(a.name, (k_proj_rows<KQB, NCG, EP>), c.grid, c.plan.wpb * 64, c.lds, stream, a, c.plan);
     return magic::launch_status();
 }

@@ -133,13 +133,7 @@ extern "C" int magic_negative_filter(int64_t n_nodes, const int32_t *out_ptr, co
     if (!out_ptr || !in_ptr || !cand_src || !cand_dst || !accept) return MAGIC_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     constexpr size_t lds = (size_t)NEG_SLOTS * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_negative_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return MAGIC_ERR_RUNTIME;
-        attr_set = true;
-    }
+    if (magic::ensure_dynamic_lds((const void *)k_negative_filter, lds) != MAGIC_OK) return MAGIC_ERR_RUNTIME;
     NegArgs a;
     a.n = n_nodes;
     a.out_ptr = out_ptr, a.out_dst = out_dst, a.in_ptr = in_ptr, a.in_src = in_src;

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops  # noqa: F401  (ops registers torch.ops.magic.*)
+from .parallel import collectives_off
 
 
 def _as_device_f32(x, device) -> torch.Tensor:
@@ -168,7 +169,7 @@ def exchange_and_merge_blocks(d: torch.Tensor, i: torch.Tensor, group=None):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     q, k = d.shape
-    if world == 1:
+    if collectives_off(world):
         return d, i, q
     per = (q + world - 1) // world
     pad = per * world - q
@@ -186,7 +187,7 @@ def gather_blocks(block: torch.Tensor, q: int, group=None) -> torch.Tensor:
     """All-gather of the ranks' row blocks, cut back to the first ``q`` rows."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    if world == 1:
+    if collectives_off(world):
         return block[:q]
     out = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
     dist.all_gather_into_tensor(out, block.contiguous(), group=group)

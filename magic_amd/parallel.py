@@ -10,10 +10,18 @@ with one ``cat`` and unpacked with one multi-tensor copy; a single-rank run does
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, Optional
 
 import torch
 import torch.distributed as dist
+
+
+def collectives_off(world: int) -> bool:
+    """A single-rank group skips its collectives (they are identities) -- unless MAGIC_FORCE_COLLECTIVES=1 asks
+    for them anyway, which is how the RCCL call path (dtypes, shapes, in-place semantics) is exercised on a
+    one-GPU machine."""
+    return world == 1 and os.environ.get("MAGIC_FORCE_COLLECTIVES") != "1"
 
 
 class FlatGradAllReduce:
@@ -39,7 +47,7 @@ class FlatGradAllReduce:
 
     def allreduce(self):
         """Average the gradients over the ranks: one collective on the whole buffer."""
-        if self.world == 1:
+        if collectives_off(self.world):
             return
         self.pack()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -53,7 +61,7 @@ class FlatGradAllReduce:
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None):
     """Make every replica start from rank ``src``'s weights (one flat broadcast)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or collectives_off(dist.get_world_size(group)):
         return
     tensors = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
     flat = torch.cat([t.reshape(-1).float() for t in tensors])
@@ -76,7 +84,7 @@ def embed_graphs(embed_fn, graphs, out_width: int, device, group=None):
     bit-identical to what a single process computes for that graph.
 
     ``embed_fn(g) -> [g.num_nodes(), out_width]`` float32 tensor on ``device``."""
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = dist.is_available() and dist.is_initialized() and not collectives_off(dist.get_world_size(group))
     world = dist.get_world_size(group) if multi else 1
     rank = dist.get_rank(group) if multi else 0
     outs = []
@@ -102,7 +110,7 @@ def gather_rows(rows: torch.Tensor, counts, group=None) -> torch.Tensor:
     rank = dist.get_rank(group)
     counts = [int(c) for c in counts]
     assert len(counts) == world and rows.shape[0] >= counts[rank]
-    if world == 1:
+    if collectives_off(world):
         return rows[:counts[0]]
     cmax = max(counts)
     send = torch.zeros((cmax,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
