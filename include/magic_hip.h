@@ -55,6 +55,9 @@ int magic_prof_reset(void);
 /* host buffers; returns number of distinct kernels written (<= max_entries) or <0 */
 int magic_prof_read(int max_entries, char *names /* max_entries x 64 bytes */,
                     int64_t *launches, double *total_ms);
+/* the names of the bracketed launches in launch order, oldest first (host buffer); returns the number of
+ * launches recorded since the last reset (which may exceed max_entries: only the first max_entries are written) */
+int magic_prof_sequence(int max_entries, char *names /* max_entries x 64 bytes */);
 
 /* ------------------------------------------------------------------------------------
  * CSC + CSR construction: stable counting sort of the COO edge list by destination and
@@ -434,9 +437,17 @@ int magic_edge_head_bwd(int64_t n_rows, int32_t width, const float *h_pre, int64
 /* ------------------------------------------------------------------------------------
  * Brute-force k nearest neighbours (Euclidean), replacing
  * sklearn.neighbors.NearestNeighbors(...).kneighbors at model/eval.py:154,158 and
- * :306,311.  Squared distances |q|^2 - 2 q.t + |t|^2 are formed in float64 on the f64
- * matrix cores from float32 inputs (as scikit-learn's float32 path does), the k
- * smallest per query are kept, ordered by (distance, train index), then sqrt.
+ * :306,311.  The result is the exact float64 one -- squared distances |q|^2 - 2 q.t + |t|^2
+ * of the float32 inputs evaluated in float64 (as scikit-learn's float32 path does), the k
+ * smallest per query ordered by (distance, train index), then sqrt -- found in two stages:
+ * a filter sweeps every (query, train row) pair on the bf16 matrix cores with float32
+ * operands split into three bf16 pieces (six products per float32-grade product) and keeps a
+ * short candidate list per query; the float64 keys of the candidates are then recomputed and
+ * an error bound proves, per query, that no dropped row can belong to the k nearest.  Queries
+ * whose proof fails, searches with lists too long for the filter's LDS and train sets under
+ * 4,096 rows take a full sweep on the f64 matrix cores instead.  Either way the reported
+ * key of a (query, row) pair comes from one scalar float64 expression, so shard results merge
+ * into the single-search result bit for bit.
  * `train_index_offset` is added to every returned index (row offset of this shard of the
  * train set).  magic_knn_merge combines `n_parts` such results (e.g. one per train
  * shard / per GPU) into the global k best, same order rule.

@@ -33,6 +33,7 @@ SYMBOLS = {
     "magic_prof_enable": (c_i32, [c_i32]),
     "magic_prof_reset": (c_i32, []),
     "magic_prof_read": (c_i32, [c_i32, C.c_char_p, C.POINTER(c_i64), C.POINTER(C.c_double)]),
+    "magic_prof_sequence": (c_i32, [c_i32, C.c_char_p]),
     "magic_csr_build_workspace_bytes": (c_i32, [c_i64, c_i64, C.POINTER(c_sz)]),
     "magic_csr_build": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_concat_offset": (c_i32, [c_i32, c_i32, c_vp, c_i64, c_vp]),
@@ -177,6 +178,15 @@ def prof_read(max_entries: int = 64):
         nm = names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()
         out[nm] = (int(launches[i]), float(total[i]))
     return out
+
+
+def prof_sequence(max_entries: int = 4096):
+    """Names of the timed launches in launch order since the last reset."""
+    names = C.create_string_buffer(max_entries * 64)
+    n = load().magic_prof_sequence(max_entries, names)
+    if n < 0:
+        _check(n, "magic_prof_sequence")
+    return [names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode() for i in range(min(n, max_entries))]
 
 
 # ------------------------------------------------------------------------------------- CSR

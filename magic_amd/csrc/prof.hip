@@ -140,4 +140,17 @@ int magic_prof_read(int max_entries, char *names, int64_t *launches, double *tot
     return n;
 }
 
+int magic_prof_sequence(int max_entries, char *names) {
+    if (max_entries < 0 || (max_entries > 0 && !names)) return MAGIC_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(magic::g_mu);
+    int n = 0;
+    for (auto &s : magic::g_spans) {
+        if (n >= max_entries) break;
+        std::strncpy(names + (size_t)n * 64, s.name, 63);
+        names[(size_t)n * 64 + 63] = 0;
+        ++n;
+    }
+    return (int)magic::g_spans.size();
+}
+
 }  // extern "C"

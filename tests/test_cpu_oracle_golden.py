@@ -539,3 +539,42 @@ def test_entity_level_loaders_read_the_parser_outputs(tmp_path):
     pickle.dump([np.arange(3)], open(base / "evil.pkl", "wb"))          # needs numpy globals to load
     with pytest.raises(pickle.UnpicklingError):
         L.load_plain_pickle(str(base / "evil.pkl"))
+
+
+def test_oracle_sparse_ops_match_scipy_sparse_products():
+    """Independent restatement of the two DGL operators the GAT layer rests on, in scipy.sparse: with A the
+    [N, E] destination incidence matrix, the per-destination softmax is exp(e - rowmax) / (A exp(e - rowmax))
+    and the aggregation is the sparse product (dst, src, a) @ hs per head.  Also the softmax backward identity
+    DGL's EdgeSoftmax uses (g_e = a * (g - sum_seg a * g)) against autograd through the restatement."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(11)
+    for n, e, heads, width in ((50, 400, 4, 16), (300, 900, 1, 8), (64, 64, 4, 4)):
+        src = rng.integers(0, n, e)
+        dst = rng.integers(0, max(1, n - n // 4), e)             # the last quarter of the nodes has no in-edges
+        dst[: e // 5] = 0                                        # a hub
+        logits = rng.standard_normal((e, heads, 1)) * 3.0
+        hs = rng.standard_normal((n, heads, width))
+        ts, td = torch.from_numpy(src), torch.from_numpy(dst)
+        a = O.edge_softmax(td, torch.from_numpy(logits), n).numpy()
+        inc = sp.csr_matrix((np.ones(e), (dst, np.arange(e))), shape=(n, e))
+        for h in range(heads):
+            x = logits[:, h, 0]
+            rowmax = np.full(n, -np.inf)
+            np.maximum.at(rowmax, dst, x)
+            ex = np.exp(x - rowmax[dst])
+            want = ex / (inc @ ex)[dst]
+            assert np.abs(a[:, h, 0] - want).max() < 1e-14
+            assert np.abs(inc @ a[:, h, 0] - (np.bincount(dst, minlength=n) > 0)).max() < 1e-12   # rows sum to 1
+            adj = sp.csr_matrix((a[:, h, 0], (dst, src)), shape=(n, n))      # duplicate (dst, src) pairs add up
+            got = O.u_mul_e_sum(ts, td, torch.from_numpy(hs), torch.from_numpy(a), n).numpy()[:, h]
+            assert np.abs(got - adj @ hs[:, h]).max() < 1e-12
+        assert not got[n - n // 4:].any() if n // 4 else True                # no in-edges -> zeros
+        # softmax backward: autograd through the restatement vs the closed form on segment sums
+        lt = torch.from_numpy(logits).requires_grad_(True)
+        g = torch.from_numpy(rng.standard_normal((e, heads, 1)))
+        at = O.edge_softmax(td, lt, n)
+        (at * g).sum().backward()
+        ag = (at.detach() * g).numpy()[:, :, 0]
+        seg = np.stack([inc @ ag[:, h] for h in range(heads)], 1)
+        want_grad = ag - at.detach().numpy()[:, :, 0] * seg[dst]
+        assert np.abs(lt.grad.numpy()[:, :, 0] - want_grad).max() < 1e-12

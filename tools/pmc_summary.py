@@ -8,11 +8,15 @@ from collections import defaultdict
 
 def summarise(pattern):
     acc = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(pattern):
+    for f in glob.glob(pattern, recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("magic::", "")
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+    out = {}
+    for k, cs in acc.items():
+        out[k] = {c: sum(v) / len(v) for c, v in cs.items()}
+        out[k]["_count"] = max(len(v) for v in cs.values())
+    return out
 
 
 if __name__ == "__main__":
@@ -24,4 +28,6 @@ if __name__ == "__main__":
     for k in sorted(keys):
         print(k)
         for c, v in sorted(out[k].items()):
+            if c == "_count":
+                continue
             print(f"    {c:32s} {v:16.1f}")
