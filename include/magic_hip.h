@@ -333,7 +333,8 @@ int magic_sce_fwd_bwd_static(int64_t n_rows, int32_t n_dim, int64_t n_mask, cons
  * graph.ndata['type']; ids outside that range belong to no type), the per-type rows
  * concatenated, out [n_types * width], zeros for a type without nodes (:59-72; Unicorn-Wget:
  * 8 types x 256).  The reference's 'max' read-out returns a (values, indices) tuple and is not
- * provided.  One pass over feat, fixed summation order, no host synchronisation.  n_types <= 32.
+ * provided.  One pass over feat, fixed summation order, no host synchronisation (32 types per pair of launches; an empty
+ * node set gives NaN for the mean over all nodes, as torch does, and zeros otherwise).
  * ---------------------------------------------------------------------------------- */
 size_t magic_readout_workspace_bytes(int64_t n_rows, int32_t width, int32_t n_types);
 int magic_readout(int64_t n_rows, int32_t width, const float *feat, int64_t ld_feat,
@@ -395,7 +396,9 @@ int magic_negative_filter(int64_t n_nodes, const int32_t *out_ptr, const int32_t
  *   exp_avg += (1 - beta1) (g - exp_avg);  exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) g^2;
  *   param -= lr / (1 - beta1^t) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^t) + eps)
  * and *step_device = t afterwards (int64 in device memory: a step recorded into a HIP graph
- * counts on its own).  `slots` is a HOST array of n_tensors entries (contiguous float32 device
+ * counts on its own).  The hyper-parameters are doubles and the bias corrections 1 - beta^t and the step size
+ * lr / (1 - beta1^t) are formed in double before they are rounded to float (torch forms them from Python
+ * floats), the element-wise updates run in float.  `slots` is a HOST array of n_tensors entries (contiguous float32 device
  * tensors); the pointers are passed to the kernels by value, 64 tensors per launch.
  * ---------------------------------------------------------------------------------- */
 typedef struct magic_adam_slot {
@@ -405,8 +408,8 @@ typedef struct magic_adam_slot {
     float *exp_avg_sq;
     int64_t n;
 } magic_adam_slot;
-int magic_adam_step(int32_t n_tensors, const magic_adam_slot *slots, int64_t *step_device, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, void *stream);
+int magic_adam_step(int32_t n_tensors, const magic_adam_slot *slots, int64_t *step_device, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Tail of the sampled edge-reconstruction loss (model/autoencoder.py:257-266 through the

@@ -46,7 +46,7 @@ SYMBOLS = {
                                     c_vp, c_sz, c_vp]),
     "magic_edge_head_bwd": (c_i32, [c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp,
                                     c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "magic_adam_step": (c_i32, [c_i32, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    "magic_adam_step": (c_i32, [c_i32, c_vp, c_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_vp]),
     "magic_proj_fwd": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_i64,
                                c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "magic_proj_fwd_workspace_bytes": (c_sz, [c_i32, c_i32]),

@@ -21,16 +21,18 @@ struct AdamBatch {
 };
 static_assert(sizeof(AdamBatch) <= 3584, "kernel arguments are limited to 4 KB");
 
-__global__ __launch_bounds__(256) void k_adam(AdamBatch b, const int64_t *__restrict__ step, float lr, float beta1,
-                                              float beta2, float eps, float weight_decay) {
+__global__ __launch_bounds__(256) void k_adam(AdamBatch b, const int64_t *__restrict__ step, double lr_d, double beta1_d,
+                                              double beta2_d, float eps, float weight_decay) {
     // slot of this block: the ranges are ascending, a linear walk over at most 64 entries
     int s = 0;
     while (s + 1 < b.n_slots && (int)blockIdx.x >= b.first_block[s + 1]) ++s;
     const magic_adam_slot sl = b.slot[s];
     const int64_t base = (int64_t)((int)blockIdx.x - b.first_block[s]) * ADAM_CHUNK;
-    const float t = (float)(step[0] + 1);
-    const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
-    const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+    // bias corrections and step size in double (two pow per block), rounded once
+    const double t = (double)(step[0] + 1);
+    const double bc1 = 1.0 - pow(beta1_d, t), bc2 = 1.0 - pow(beta2_d, t);
+    const float step_size = (float)(lr_d / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
 #pragma unroll
     for (int j = 0; j < ADAM_CHUNK / 256; ++j) {
         const int64_t i = base + j * 256 + threadIdx.x;
@@ -55,8 +57,8 @@ __global__ void k_adam_tick(int64_t *step) {
 
 }  // namespace
 
-extern "C" int magic_adam_step(int32_t n_tensors, const magic_adam_slot *slots, int64_t *step_device, float lr,
-                               float beta1, float beta2, float eps, float weight_decay, void *stream_) {
+extern "C" int magic_adam_step(int32_t n_tensors, const magic_adam_slot *slots, int64_t *step_device, double lr,
+                               double beta1, double beta2, double eps, double weight_decay, void *stream_) {
     if (n_tensors < 0 || !step_device || (n_tensors > 0 && !slots)) return MAGIC_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     for (int32_t s0 = 0; s0 < n_tensors; s0 += ADAM_SLOTS) {
@@ -77,8 +79,8 @@ extern "C" int magic_adam_step(int32_t n_tensors, const magic_adam_slot *slots, 
         for (int s = b.n_slots; s <= ADAM_SLOTS; ++s) b.first_block[s] = (int32_t)blocks;
         for (int s = b.n_slots; s < ADAM_SLOTS; ++s) b.slot[s] = magic_adam_slot{nullptr, nullptr, nullptr, nullptr, 0};
         if (b.n_slots == 0) continue;
-        MAGIC_LAUNCH("adam_step", k_adam, (unsigned)blocks, 256, 0, stream, b, step_device, lr, beta1, beta2, eps,
-                     weight_decay);
+        MAGIC_LAUNCH("adam_step", k_adam, (unsigned)blocks, 256, 0, stream, b, step_device, lr, beta1, beta2, (float)eps,
+                     (float)weight_decay);
     }
     MAGIC_LAUNCH("adam_tick", k_adam_tick, 1, 64, 0, stream, step_device);
     return magic::launch_status();

@@ -85,7 +85,7 @@ int ensure_dynamic_lds(const void *kernel, size_t bytes) {
 
 extern "C" {
 
-int magic_abi_version(void) { return 2; }
+int magic_abi_version(void) { return 3; }
 
 const char *magic_status_string(int status) {
     switch (status) {

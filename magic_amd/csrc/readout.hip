@@ -17,6 +17,7 @@ struct ReadoutArgs {
     const float *feat;
     int64_t ld;
     const int64_t *types;  // or null: one type
+    int64_t type0;         // first type of this launch's window (wider type sets take several launches)
     int grid;
     int64_t rows_per_block;
     float *ws_sum;    // [grid, sub, n_types, width]
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256) void k_readout_partial(ReadoutArgs a) {
     if (threadIdx.x < kMaxTypes) cnt[threadIdx.x] = 0;
     __syncthreads();
     for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {  // per-type row counts (integer adds: any order)
-        const int64_t t = a.types ? a.types[r] : 0;
+        const int64_t t = a.types ? a.types[r] - a.type0 : 0;
         if (t >= 0 && t < a.n_types) atomicAdd(&cnt[t], 1);
     }
     for (int c0 = 0; c0 < a.width; c0 += a.cw) {
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void k_readout_partial(ReadoutArgs a) {
         const int col = c0 + c;
         if (col < a.width) {
             for (int64_t r = r0 + ss; r < r1; r += a.sub) {  // this sub-stream's rows, ascending
-                const int64_t t = a.types ? a.types[r] : 0;
+                const int64_t t = a.types ? a.types[r] - a.type0 : 0;
                 if (t >= 0 && t < a.n_types) tbl[(ss * a.n_types + (int)t) * a.cw + c] += a.feat[r * a.ld + col];
             }
             for (int t = 0; t < a.n_types; ++t)
@@ -82,7 +83,8 @@ extern "C" {
 
 size_t magic_readout_workspace_bytes(int64_t n_rows, int32_t width, int32_t n_types) {
     if (n_rows <= 0 || width <= 0) return 256;
-    const int T = n_types > 0 ? n_types : 1;
+    int T = n_types > 0 ? n_types : 1;
+    if (T > kMaxTypes) T = kMaxTypes;  // wider type sets run in windows of 32 types
     const size_t g = readout_grid(n_rows), sub = 256 / readout_cw(width);
     return magic::align_up(g * sub * T * (size_t)width * sizeof(float)) + magic::align_up(g * T * sizeof(int32_t)) + 256;
 }
@@ -92,17 +94,19 @@ int magic_readout(int64_t n_rows, int32_t width, const float *feat, int64_t ld_f
     if (n_rows < 0 || width <= 0 || n_types < 0 || !out || (n_rows > 0 && (!feat || ld_feat < width)))
         return MAGIC_ERR_INVALID_ARG;
     if (n_types > 0 && !node_type && n_rows > 0) return MAGIC_ERR_INVALID_ARG;
-    if (n_types > kMaxTypes) return MAGIC_ERR_UNSUPPORTED;
     hipStream_t stream = (hipStream_t)stream_;
     const int T = n_types > 0 ? n_types : 1;
-    if (n_rows == 0) {  // torch's mean of no rows is NaN; per-type read-outs of no rows are zeros
-        if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)T * width, stream) != hipSuccess) return MAGIC_ERR_RUNTIME;
+    if (n_rows == 0) {
+        // no rows: the mean over all nodes is NaN as torch's mean of an empty tensor is (utils/poolers.py:58),
+        // the sum is 0; per-type read-outs start from zeros (utils/poolers.py:62) and stay zeros
+        const bool nan = n_types == 0 && mean;
+        if (hipMemsetD32Async((hipDeviceptr_t)out, nan ? 0x7fc00000 : 0, (size_t)T * width, stream) != hipSuccess)
+            return MAGIC_ERR_RUNTIME;
         return MAGIC_OK;
     }
     ReadoutArgs a;
     a.n = n_rows;
     a.width = width;
-    a.n_types = T;
     a.cw = readout_cw(width);
     a.sub = 256 / a.cw;
     a.feat = feat;
@@ -111,14 +115,19 @@ int magic_readout(int64_t n_rows, int32_t width, const float *feat, int64_t ld_f
     a.grid = readout_grid(n_rows);
     a.rows_per_block = kRowsPerBlock;
     a.mean = mean;
-    a.out = out;
+    const int Tw = T < kMaxTypes ? T : kMaxTypes;  // types per launch: the block's LDS table holds 32 of them
     magic::Arena ar(workspace, workspace_bytes);
-    a.ws_sum = ar.take<float>((size_t)a.grid * a.sub * T * width);
-    a.ws_cnt = ar.take<int32_t>((size_t)a.grid * T);
+    a.ws_sum = ar.take<float>((size_t)a.grid * a.sub * Tw * width);
+    a.ws_cnt = ar.take<int32_t>((size_t)a.grid * Tw);
     if (!ar.ok() || !a.ws_sum || !a.ws_cnt) return MAGIC_ERR_WORKSPACE;
-    const size_t sh = (size_t)256 * T * sizeof(float);  // sub * T * cw floats
-    MAGIC_LAUNCH("readout_partial", k_readout_partial, a.grid, 256, sh, stream, a);
-    MAGIC_LAUNCH("readout_final", k_readout_final, (T * width + 255) / 256, 256, 0, stream, a);
+    for (int t0 = 0; t0 < T; t0 += kMaxTypes) {  // (stream order: a window's partial tables are consumed before the next)
+        a.type0 = t0;
+        a.n_types = T - t0 < kMaxTypes ? T - t0 : kMaxTypes;
+        a.out = out + (size_t)t0 * width;
+        const size_t sh = (size_t)256 * a.n_types * sizeof(float);  // sub * n_types * cw floats
+        MAGIC_LAUNCH("readout_partial", k_readout_partial, a.grid, 256, sh, stream, a);
+        MAGIC_LAUNCH("readout_final", k_readout_final, (a.n_types * width + 255) / 256, 256, 0, stream, a);
+    }
     return magic::launch_status();
 }
 

@@ -53,29 +53,38 @@ def load_batch_level_dataset(dataset_name):
             "e_feat": edge_feature_dim}
 
 
-# bytes of one-hot edge attributes kept for reuse across calls (per process)
-_EDGE_ATTR_CACHE_BYTES = 16 << 30
+# One-hot edge attributes kept for reuse across calls: a budget per process, MAGIC_EDGE_ATTR_CACHE_MB megabytes
+# (default 4096; 0 switches the cache off).  A StreamSpot-sized graph holds 13.6 MB this way, so the default keeps
+# about 300 training graphs' attributes beside the working set of a step (under 2 % of the 288 GB of an MI355X).
+_EDGE_ATTR_CACHE_BYTES = int(float(os.environ.get("MAGIC_EDGE_ATTR_CACHE_MB", "4096")) * (1 << 20))
 _edge_attr_bytes = 0
+
+
+def _release_edge_attr(nbytes: int):
+    global _edge_attr_bytes
+    _edge_attr_bytes -= nbytes
 
 
 def _edge_one_hot(g: Graph, edge_feature_dim: int) -> torch.Tensor:
     """``one_hot(edata['type']).float()``, kept on the source graph while the type tensor and the attribute
     tensor stay untouched (version counters): the training loops call ``transform_graph`` on the same
     graphs every epoch, nothing on the training path writes into the edge attributes, and at the
-    StreamSpot shape the twelve one-hot matrices of a batch are 160 MB and 24 launches per step."""
+    StreamSpot shape the twelve one-hot matrices of a batch are 160 MB and 24 launches per step.
+    The budget is given back when an entry is replaced and when the tensor that holds it is freed (with its graph)."""
     global _edge_attr_bytes
     t = g.edata["type"]
     hit = g._cache.get("edge_onehot")
     if hit is not None:
-        t_ref, t_ver, dim, attr, a_ver = hit
+        t_ref, t_ver, dim, attr, a_ver, fin = hit
         if t_ref() is t and t_ver == t._version and dim == edge_feature_dim and a_ver == attr._version:
             return attr
-        _edge_attr_bytes -= attr.numel() * 4
+        fin()                                   # gives the bytes back now (a finalizer runs once)
         del g._cache["edge_onehot"]
     attr = _one_hot_float(t, edge_feature_dim)
     nbytes = attr.numel() * 4
     if t.is_cuda and _edge_attr_bytes + nbytes <= _EDGE_ATTR_CACHE_BYTES:
-        g._cache["edge_onehot"] = (weakref.ref(t), t._version, edge_feature_dim, attr, attr._version)
+        fin = weakref.finalize(attr, _release_edge_attr, nbytes)
+        g._cache["edge_onehot"] = (weakref.ref(t), t._version, edge_feature_dim, attr, attr._version, fin)
         _edge_attr_bytes += nbytes
     return attr
 

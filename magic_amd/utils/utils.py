@@ -118,7 +118,8 @@ def _first_occurrences(vals: np.ndarray, n: int) -> np.ndarray:
     if buf.size < n:
         buf = _first_seen["buf"] = np.empty(n, dtype=np.int32)
     idx = np.arange(m, dtype=np.int32)
-    buf[vals[::-1]] = idx[::-1]          # of equal values the earliest position is written last and stays
+    buf[vals] = np.iinfo(np.int32).max   # (one value for every write: the result does not depend on write order)
+    np.minimum.at(buf, vals, idx)        # smallest position of every value
     return np.nonzero(buf[vals] == idx)[0]
 
 

@@ -211,17 +211,53 @@ def test_fused_adam_equals_torch_adam(cuda):
         om.step()
         orf.step()
     for i, (pm, pr) in enumerate(zip(mine, ref)):
-        if i == 5:
-            continue   # (skipped one step: torch counts steps per parameter, the fused kernel per group)
+        # (parameter 5 skipped one step: it is counted on its own from then on, as torch counts per parameter)
         err = (pm.detach().cpu().double() - pr.detach()).abs().max() / pr.detach().abs().max().clamp_min(1e-3)
         assert float(err) < 2e-6, (i, float(err))
     st = om.state[mine[0]]
     assert int(st["step"]) == 6 and st["exp_avg"].shape == mine[0].shape and st["exp_avg_sq"].dtype == torch.float32
     assert om.state[mine[0]]["step"] is om.state[mine[1]]["step"] and om.state[mine[65]]["step"] is not st["step"]
+    assert int(om.state[mine[5]]["step"]) == 5 and om.state[mine[5]]["step"] is not st["step"]
     sd = om.state_dict()
     om2 = FusedAdam([dict(params=mine[:60]), dict(params=mine[60:])], lr=1e-3)
     om2.load_state_dict(sd)
     assert om2.param_groups[1]["lr"] == 3e-3 and int(om2.state[mine[3]]["step"]) == 6
+    assert om2.state[mine[3]]["step"] is om2.state[mine[4]]["step"] and int(om2.state[mine[5]]["step"]) == 5
+    # stepping goes on after a load: from this class's own state dict (moved to the host, as torch.load with
+    # map_location='cpu' leaves it) and from the state dict torch.optim.Adam wrote (float counts on the host)
+    import copy
+    host_sd = copy.deepcopy(sd)
+    for v in host_sd["state"].values():
+        for k2 in v:
+            v[k2] = v[k2].cpu()
+    om3 = FusedAdam([dict(params=mine[:60]), dict(params=mine[60:])], lr=1e-3)
+    om3.load_state_dict(host_sd)
+    mine_t = [torch.nn.Parameter(p_.detach().double().cpu().float().to(cuda)) for p_ in ref]
+    om4 = FusedAdam([dict(params=mine_t[:60]), dict(params=mine_t[60:])], lr=1e-3)
+    om4.load_state_dict(orf.state_dict())
+    assert om4.state[mine_t[0]]["step"].dtype == torch.int64 and om4.state[mine_t[0]]["step"].is_cuda
+    assert om4.state[mine_t[0]]["exp_avg"].dtype == torch.float32 and int(om4.state[mine_t[5]]["step"]) == 5
+    for step in range(2):
+        for pm, pt, pr in zip(mine, mine_t, ref):
+            g = torch.randn(pm.shape, generator=gen)
+            pm.grad, pt.grad, pr.grad = g.to(cuda), g.to(cuda), g.double()
+        om3.step()
+        om4.step()
+        orf.step()
+    for i, (pm, pt, pr) in enumerate(zip(mine, mine_t, ref)):
+        scale = pr.detach().abs().max().clamp_min(1e-3)
+        assert float((pm.detach().cpu().double() - pr.detach()).abs().max() / scale) < 3e-6, i
+        assert float((pt.detach().cpu().double() - pr.detach()).abs().max() / scale) < 3e-6, i
+    # a parameter whose first gradient arrives later starts its own count at 1
+    late = torch.nn.Parameter(torch.ones(10, device=cuda))
+    early = torch.nn.Parameter(torch.ones(10, device=cuda))
+    ol = FusedAdam([late, early], lr=1e-2)
+    for k in range(3):
+        early.grad = torch.ones(10, device=cuda)
+        late.grad = torch.ones(10, device=cuda) if k == 2 else None
+        ol.step()
+    assert int(ol.state[early]["step"]) == 3 and int(ol.state[late]["step"]) == 1
+    assert abs(float(late[0]) - (1.0 - 1e-2)) < 1e-6          # first Adam step: lr * sign(g)
     # the reference's factory hands out this optimizer for a model on the GPU and torch's own on the CPU
     lin = torch.nn.Linear(4, 3)
     assert type(create_optimizer("adam", lin, 1e-3, 5e-4)) is torch.optim.Adam

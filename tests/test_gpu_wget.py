@@ -47,7 +47,7 @@ def test_readout_equals_reference_fixture(cuda):
 
 
 @pytest.mark.parametrize("n,width,n_types", [(1, 256, 8), (127, 256, 8), (129, 64, 0), (5000, 256, 8),
-                                             (3001, 40, 3), (70000, 256, 8), (999, 300, 32)])
+                                             (3001, 40, 3), (70000, 256, 8), (999, 300, 32), (2000, 64, 33), (4000, 24, 70)])
 def test_readout_against_float64(cuda, n, width, n_types):
     from magic_amd import _lib
     rng = np.random.default_rng(n + width)
@@ -76,6 +76,11 @@ def test_readout_against_float64(cuda, n, width, n_types):
         ty[::7] = -1
         want = _typed_readout_f64(view.cpu().numpy().astype(np.float64), ty, n_types, True)
         assert np.abs(got.cpu().numpy() - want).max() / (np.abs(want).max() + 1e-30) < 2e-6
+    # no rows: torch's mean over an empty node set is NaN, its sum and the per-type read-outs are zeros
+    empty = ft[:0]
+    assert bool(torch.isnan(_lib.readout(empty, None, 0, True)).all())
+    assert not bool(_lib.readout(empty, None, 0, False).any())
+    assert not bool(_lib.readout(empty, tt[:0], 3, True).any())
 
 
 def test_wget_pooled_graph_embedding_matches_oracle(cuda):
@@ -171,3 +176,22 @@ def test_wget_largest_graph_properties(wget_max, cuda):
     lm = float(run()[0])
     shift(1)
     assert abs((lp - lm) / (2 * eps) - norm) / norm < 0.05
+
+
+def test_edge_attribute_cache_returns_its_budget(cuda):
+    """transform_graph keeps the one-hot edge attributes of a GPU graph for the next call; the bytes count
+    against a per-process budget and come back when the entry is replaced or the graph is freed."""
+    import gc
+    from magic_amd.utils import loaddata as L
+    src, dst, nt, et = small_graph(300, 1500, 8, 4, seed=21)
+    g = to_graph(src, dst, 300, nt, et, 8, 4, cuda)
+    before = L._edge_attr_bytes
+    a1 = L.transform_graph(g, 8, 4).edata["attr"]
+    a2 = L.transform_graph(g, 8, 4).edata["attr"]
+    assert a1 is a2 and L._edge_attr_bytes == before + 1500 * 4 * 4
+    g.edata["type"] = g.edata["type"].clone()            # another type tensor: the entry is rebuilt, not leaked
+    a3 = L.transform_graph(g, 8, 4).edata["attr"]
+    assert a3 is not a1 and torch.equal(a3, a1) and L._edge_attr_bytes == before + 1500 * 4 * 4
+    del a1, a2, a3, g
+    gc.collect()
+    assert L._edge_attr_bytes == before
