@@ -14,7 +14,8 @@ from typing import Dict, Optional, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmagic_hip.so")
+# MAGIC_HIP_LIBRARY: another build of the library (kernel tuning: two builds timed in turn on one machine)
+_LIB_PATH = os.environ.get("MAGIC_HIP_LIBRARY") or os.path.join(_HERE, "libmagic_hip.so")
 _lib = None
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t

@@ -41,8 +41,19 @@ struct FwdArgs {
     float *stat;  // [N,H,2] per destination and head: (et, max + log sum exp of its in-edge logits), or null
     float *x;         // [E,H] raw logits (workspace)
     float *ws_stats;  // [n_chunks,H,2]
-    float *ws_acc;    // [n_chunks,C]
+    float *ws_acc;    // [n_chunks * agg_split,C]
+    int agg_split;    // waves that share one chunk in the aggregation (graphs with few chunks)
 };
+
+// A chunk is 256 edges, taken four gathered rows at a time by one wave: a graph with few heavy edges leaves
+// most of the chip idle behind 64 dependent round trips per wave.  Below ~1,500 chunks every chunk is cut
+// into 2, 4 or 8 runs with a wave each; the finish step adds the runs in order.
+inline int agg_split_for(int n_chunks) {
+    if (n_chunks >= 1536 || n_chunks <= 0) return 1;
+    if (n_chunks >= 768) return 2;
+    if (n_chunks >= 384) return 4;
+    return 8;
+}
 
 constexpr int SEG = 64;  // longest segment a lane group takes (the plan's light_max may not exceed it)
 
@@ -347,10 +358,16 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
     constexpr int NSG = 64 / G;
     constexpr int C = G * 4;
     const int lane = threadIdx.x & 63;
-    const int c = xcd_chunk(threadIdx.x >> 6);
+    const int unit = xcd_chunk(threadIdx.x >> 6);  // (chunk, run of the chunk)
+    const int c = unit / a.agg_split, run = unit % a.agg_split;
     if (c >= a.plan.n_chunks) return;
     const int slot = a.plan.chunk_node[c];
-    const int beg = a.plan.chunk_beg[c], end = a.plan.chunk_end[c];
+    int beg = a.plan.chunk_beg[c], end = a.plan.chunk_end[c];
+    if (a.agg_split > 1) {
+        const int per = (end - beg + a.agg_split - 1) / a.agg_split;
+        beg = min(beg + run * per, end);
+        end = min(beg + per, end);
+    }
     float mm[H], ss[H];
     node_stats<H>(a, slot, lane, mm, ss);
     const int g = lane % G, sg = lane / G, h = g / LPH;
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
         }
     const float inv = 1.f / s;
     const bool writer = (g % LPH) == 0;
-    if (a.stat && c == a.plan.heavy_cptr[slot] && sg == 0 && writer) {  // the node's first chunk records its statistics
+    if (a.stat && c == a.plan.heavy_cptr[slot] && run == 0 && sg == 0 && writer) {  // the node's first chunk records its statistics
         const int v = a.plan.heavy_node[slot];
         *reinterpret_cast<float2 *>(a.stat + ((int64_t)v * H + h) * 2) =
             make_float2(a.et[(int64_t)v * a.ld_s + h], m + logf(s));
@@ -393,7 +410,7 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
         fma4(acc, w, r);
     }
     acc = substream_sum4<G>(acc);
-    if (sg == 0) st4(a.ws_acc + (int64_t)c * C + g * 4, acc);
+    if (sg == 0) st4(a.ws_acc + (int64_t)unit * C + g * 4, acc);
 }
 
 // Heavy segments, step 3: one block per heavy node sums its chunk partials in a fixed order
@@ -406,7 +423,7 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_finish(FwdArgs a) {
     __shared__ float4 part[256];
     const int slot = blockIdx.x;
     const int g = threadIdx.x % G, sg = threadIdx.x / G;
-    const int c0 = a.plan.heavy_cptr[slot], c1 = a.plan.heavy_cptr[slot + 1];
+    const int c0 = a.plan.heavy_cptr[slot] * a.agg_split, c1 = a.plan.heavy_cptr[slot + 1] * a.agg_split;
     float4 acc = f4zero();
     for (int c = c0 + sg; c < c1; c += NSGB) add4(acc, ld4(a.ws_acc + (int64_t)c * C + g * 4));
     part[threadIdx.x] = acc;
@@ -428,7 +445,8 @@ int launch_fwd(const FwdArgs &a, hipStream_t stream) {
     if (a.plan.n_chunks > 0) {
         int cgrid = chunk_grid(a.plan.n_chunks);
         MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_heavy_stats", H, LPH) : "gat_fwd_heavy_stats", (k_fwd_heavy_stats<H, TABLE>), cgrid, 256, 0, stream, a);
-        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_heavy_agg", H, LPH) : "gat_fwd_heavy_agg", (k_fwd_heavy_agg<H, LPH>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_heavy_agg", H, LPH) : "gat_fwd_heavy_agg", (k_fwd_heavy_agg<H, LPH>),
+                     chunk_grid(a.plan.n_chunks * a.agg_split), 256, 0, stream, a);
         MAGIC_LAUNCH("gat_fwd_heavy_finish", (k_fwd_heavy_finish<H, LPH>), a.plan.n_heavy, 256, 0, stream, a);
     }
     return launch_status();
@@ -442,7 +460,7 @@ size_t magic_gat_fwd_workspace_bytes(int32_t n_edges, int32_t n_chunks, int32_t 
     size_t b = magic::align_up((size_t)(n_edges > 0 ? n_edges : 1) * H * sizeof(float));
     if (n_chunks > 0)
         b += magic::align_up((size_t)n_chunks * H * 2 * sizeof(float)) +
-             magic::align_up((size_t)n_chunks * H * D * sizeof(float));
+             magic::align_up((size_t)n_chunks * magic::agg_split_for(n_chunks) * H * D * sizeof(float));
     return b + 256;
 }
 
@@ -493,11 +511,12 @@ int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     a.attn = attn;
     a.stat = stat;
     a.ws_stats = a.ws_acc = nullptr;
+    a.agg_split = agg_split_for(a.plan.n_chunks);
     Arena ar(workspace, workspace_bytes);
     a.x = ar.take<float>((size_t)(E > 0 ? E : 1) * H);
     if (a.plan.n_chunks > 0) {
         a.ws_stats = ar.take<float>((size_t)a.plan.n_chunks * H * 2);
-        a.ws_acc = ar.take<float>((size_t)a.plan.n_chunks * C);
+        a.ws_acc = ar.take<float>((size_t)a.plan.n_chunks * a.agg_split * C);
     }
     if (!ar.ok() || !a.x) return MAGIC_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;

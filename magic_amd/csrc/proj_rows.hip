@@ -346,7 +346,12 @@ namespace magic {
 // those shapes are MFMA-bound, not HBM-bound).  `n_part` receives the number of partial-sum rows
 // one window writes (one per wave of the grid), `n_win` the number of windows: part_col is
 // [n_part, C], part_prelu [n_win, n_part].  With `dry_run` nothing is launched.
+int proj_strip_try(const ProjArgs &a0, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream);
+
 int proj_rows_try(const ProjArgs &a0, int64_t *n_part, int *n_win, bool dry_run, hipStream_t stream) {
+    // the streaming kernel (coalesced loads, tile turned into operands in LDS) takes the shapes it covers
+    const int st_strip = proj_strip_try(a0, n_part, n_win, dry_run, stream);
+    if (st_strip != MAGIC_ERR_UNSUPPORTED) return st_strip;
     ProjArgs a = a0;
     a.col0 = 0;
     const bool ep = has_epilogue(a);

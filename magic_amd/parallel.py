@@ -32,6 +32,7 @@ class FlatGradAllReduce:
         self.sizes = [p.numel() for p in self.params]
         dev = self.params[0].device
         self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=dev)
+        self._comm_stream = None
 
     def zero(self):
         """``optimizer.zero_grad(set_to_none=True)``: autograd then stores each gradient instead
@@ -45,10 +46,7 @@ class FlatGradAllReduce:
         torch.cat(parts, out=self.flat)
         return self.flat
 
-    def allreduce(self):
-        """Average the gradients over the ranks: one collective on the whole buffer."""
-        if collectives_off(self.world):
-            return
+    def _exchange(self):
         self.pack()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.div_(self.world)
@@ -57,6 +55,26 @@ class FlatGradAllReduce:
             if p.grad is None:
                 p.grad = torch.empty_like(p)
         torch._foreach_copy_([p.grad for p in self.params], [v.view_as(p) for p, v in zip(self.params, views)])
+
+    def allreduce(self):
+        """Average the gradients over the ranks: one collective on the whole buffer.
+
+        On the GPU the exchange runs on a stream of its own, ordered after the caller's stream and before its
+        later work.  The collective leaves completion events behind on the stream it ran on, which the process
+        group's watchdog thread polls for some time afterwards; polling an event of a stream that has meanwhile
+        started recording a HIP graph is an error, so the exchange must never run on a stream that steps are
+        recorded on (``model.step.CapturedTrainStep`` records on the stream its eager steps ran on)."""
+        if collectives_off(self.world):
+            return
+        if not self.flat.is_cuda:
+            return self._exchange()
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.flat.device)
+        cur = torch.cuda.current_stream(self.flat.device)
+        self._comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self._comm_stream):
+            self._exchange()
+        cur.wait_stream(self._comm_stream)
 
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None):
