@@ -194,6 +194,64 @@ int magic_gat_fwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t hea
                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Coded input of the first encoder layer.  The reference feeds that layer one_hot(node type)
+ * (utils/loaddata.py:258) with the masked rows overwritten by the mask token
+ * (model/autoencoder.py:201-210), through feature dropout (model/gat.py:283):
+ *   x[u, j] = keep_j(u) * scale * (masked(u) ? token[j] : [j == type(u)]).
+ * Such a row takes one of n_dim + 1 + 2^n_dim values, so everything the layer derives linearly from
+ * it (model/gat.py:284 fc, :291-292 the head scores, :323 res_fc) is one row of a small table:
+ * row r < n_dim = a kept one of type r, row n_dim = the dropped one (zeros), row n_dim + 1 + b = the
+ * token under keep pattern b (bit j = column j kept); columns [0,C) hs | [C,C+H) eh | [C+H,C+2H) et |
+ * [C+2H,2C+2H) residual, i.e. x(r) . W^T for the augmented weight W [M, n_dim].  The *_coded entry
+ * points fetch those rows by a 4-byte code word per node (the row index) from the caches instead of
+ * gathering rows of materialised [N,C] arrays from HBM: no projection launch, no [N, n_dim] input
+ * matrix.  Results equal the dense path up to fp32 rounding.  n_dim <= 13.
+ *   magic_coded_table        the table [magic_coded_table_rows(n_dim), ld_table] from W, the token and
+ *                            scale = 1 / keep probability (1 without dropout);
+ *   magic_node_code          code words from node types [N] int64, the uint8 keep mask [N, n_dim]
+ *                            (NULL: keep all) and the masked row ids [n_mask] (distinct);
+ *   magic_gat_fwd_coded      magic_gat_fwd for such a layer (4 heads, typed edges, linear residual
+ *                            taken from the table, no attention output);
+ *   magic_gat_bwd_coded      magic_gat_bwd for it (d_y [N, >= 2C+2H] receives d_hs | d_eh | d_et as
+ *                            usual; the caller's d_pre columns are the residual's gradient);
+ *   magic_coded_weight_grad  dW [M, ld_dw] (columns [0, n_dim)) of W [M, ld_w] from d_y [N, M], and
+ *                            the mask token's gradient d_token [n_dim] (or NULL): sums of d_y rows
+ *                            grouped by code word, fixed summation order (token, n_dim and scale of
+ *                            `input` are read here; the sweeps read code and table only).
+ * ---------------------------------------------------------------------------------- */
+#define MAGIC_CODED_MAX_DIM 13
+typedef struct magic_coded_input {
+    const uint32_t *code; /* [N] table row of every node */
+    const float *table;   /* [magic_coded_table_rows(n_dim), ld_table], 16-byte aligned rows */
+    int64_t ld_table;
+    const float *token;   /* [n_dim] */
+    int32_t n_dim;
+    float scale;          /* 1 / keep probability (1 without dropout) */
+} magic_coded_input;
+int64_t magic_coded_table_rows(int32_t n_dim);
+int magic_coded_table(int32_t n_dim, int32_t m, const float *w, int64_t ld_w, const float *token, float scale,
+                      float *table, int64_t ld_table, void *stream);
+int magic_node_code(int64_t n_nodes, int32_t n_dim, const int64_t *node_type, const uint8_t *keep_mask,
+                    int64_t n_mask, const int64_t *mask_rows, uint32_t *code, void *stream);
+int magic_gat_fwd_coded(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t head_dim,
+                        const magic_plan *in_plan, const int32_t *in_src, const magic_coded_input *input,
+                        const float *ee_table, const int32_t *etype_csc, float negative_slope,
+                        const float *bias, const float *prelu_w, float *out, int64_t ld_out, float *pre,
+                        float *stat, void *workspace, size_t workspace_bytes, void *stream);
+int magic_gat_bwd_coded(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t head_dim,
+                        const magic_plan *in_plan, const int32_t *in_pos, const magic_plan *out_plan,
+                        const int32_t *out_dst, const int32_t *out_pos, const magic_coded_input *input,
+                        const float *stat, const float *ee_table, const int32_t *etype_csr, int32_t e_dim,
+                        float negative_slope, const float *pre, const float *act_out, int64_t ld_act,
+                        const float *prelu_w, const float *d_out, int64_t ld_dout, float *d_pre, int64_t ld_dpre,
+                        float *d_y, int64_t ld_dy, float *d_ee_table, float *d_bias, float *d_prelu_w,
+                        void *workspace, size_t workspace_bytes, void *stream);
+size_t magic_coded_weight_grad_workspace_bytes(int32_t m, int32_t n_dim);
+int magic_coded_weight_grad(int64_t n_nodes, int32_t m, const magic_coded_input *input, const float *dy,
+                            int64_t ld_dy, const float *w, int64_t ld_w, float *dw, int64_t ld_dw,
+                            float *d_token, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Adjoint of a row gather y = x[idx] with repeated indices (model/autoencoder.py:257-258:
  * enc_rep[sample_src], enc_rep[sample_dst]):  dst[idx[s], :] += src[s, :], idx in [0, n_rows).
  * (row, position) pairs pass through a stable radix sort over the bits a row index needs; the

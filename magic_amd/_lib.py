@@ -27,6 +27,12 @@ class MagicPlan(C.Structure):
                 ("chunk_end", c_vp), ("node_order", c_vp), ("xcd_start", c_vp)]
 
 
+class MagicCodedInput(C.Structure):
+    """``magic_coded_input`` of include/magic_hip.h."""
+    _fields_ = [("code", c_vp), ("table", c_vp), ("ld_table", c_i64), ("token", c_vp), ("n_dim", c_i32),
+                ("scale", c_f32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/magic_hip.h declares
 SYMBOLS = {
     "magic_abi_version": (c_i32, []),
@@ -72,6 +78,17 @@ SYMBOLS = {
     "magic_gat_bwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, C.POINTER(MagicPlan), c_vp,
                               c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_i64,
                               c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "magic_coded_table_rows": (c_i64, [c_i32]),
+    "magic_coded_table": (c_i32, [c_i32, c_i32, c_vp, c_i64, c_vp, c_f32, c_vp, c_i64, c_vp]),
+    "magic_node_code": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "magic_gat_fwd_coded": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, C.POINTER(MagicCodedInput),
+                                    c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "magic_gat_bwd_coded": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, C.POINTER(MagicPlan), c_vp,
+                                    c_vp, C.POINTER(MagicCodedInput), c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_i64,
+                                    c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "magic_coded_weight_grad_workspace_bytes": (c_sz, [c_i32, c_i32]),
+    "magic_coded_weight_grad": (c_i32, [c_i64, c_i32, C.POINTER(MagicCodedInput), c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
+                                        c_vp, c_vp, c_sz, c_vp]),
     "magic_sce_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "magic_sce_fwd_bwd": (c_i32, [c_i64, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32,
                                   c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -635,6 +652,134 @@ def gat_bwd(struct, H: int, D: int, hs, eh, stat, ee_table, etype_csr, ee_csc, e
                              _dev(d_pre), d_pre.stride(0), _dev(d_y), d_y.stride(0), _dev(d_table), _dev(rec),
                              _dev(d_bias), _dev(d_prelu), ws.data_ptr(), ws.numel(), _stream()), "magic_gat_bwd")
     return d_table, rec, d_bias, d_prelu
+
+
+# ------------------------------------------------------------------------------------- coded layer input
+CODED_MAX_DIM = 13  # MAGIC_CODED_MAX_DIM
+
+
+class CodedInput:
+    """The first encoder layer's input as code words (``magic_coded_input``): ``code`` [N] (int32 holding the table
+    row of every node), ``table`` [n_dim + 1 + 2^n_dim, M] (``coded_table``), ``token`` [n_dim], the dropout scale.
+    Holds the tensors alive; ``struct()`` is the ctypes view."""
+
+    def __init__(self, code: torch.Tensor, table: torch.Tensor, token: torch.Tensor, n_dim: int, scale: float):
+        assert code.dtype == torch.int32 and code.is_contiguous()
+        assert table.dtype == torch.float32 and table.stride(1) == 1 and table.stride(0) % 4 == 0
+        assert table.data_ptr() % 16 == 0 and table.shape[0] == n_dim + 1 + (1 << n_dim)
+        token = token.detach().reshape(-1).contiguous()
+        assert token.dtype == torch.float32 and token.numel() == n_dim
+        self.code, self.table, self.token, self.n_dim, self.scale = code, table, token, int(n_dim), float(scale)
+
+    def struct(self) -> MagicCodedInput:
+        ci = MagicCodedInput()
+        ci.code, ci.table, ci.ld_table = self.code.data_ptr(), self.table.data_ptr(), self.table.stride(0)
+        ci.token, ci.n_dim, ci.scale = self.token.data_ptr(), self.n_dim, self.scale
+        return ci
+
+
+def coded_table(w_aug: torch.Tensor, token: torch.Tensor, scale: float) -> torch.Tensor:
+    """[n_dim + 1 + 2^n_dim, M] table of the rows ``x . w_aug^T`` a coded input row can produce (w_aug [M, n_dim])."""
+    lib = load()
+    M, n_dim = w_aug.shape
+    assert w_aug.stride(1) == 1
+    rows = int(lib.magic_coded_table_rows(n_dim))
+    if rows == 0:
+        raise MagicHipError(f"coded input supports at most {CODED_MAX_DIM} input columns (got {n_dim})")
+    ld = (M + 3) // 4 * 4
+    tab = torch.empty(rows, ld, dtype=torch.float32, device=w_aug.device)[:, :M]
+    token = token.detach().reshape(-1).contiguous()
+    _check(lib.magic_coded_table(n_dim, M, _dev(w_aug, torch.float32, "w_aug"), w_aug.stride(0),
+                                 _dev(token, torch.float32, "token"), float(scale), _dev(tab), tab.stride(0), _stream()),
+           "magic_coded_table")
+    return tab
+
+
+def node_code(node_type: torch.Tensor, n_dim: int, keep_mask: Optional[torch.Tensor],
+              mask_rows: Optional[torch.Tensor]) -> torch.Tensor:
+    """Code words [N] (int32 holding the uint32 bit patterns) from node types, the uint8 keep mask [N, n_dim] of the
+    layer's dropout (None: keep all) and the ids of the rows that hold the mask token (None: none)."""
+    node_type = node_type.view(-1).to(torch.int64).contiguous()
+    n = node_type.numel()
+    code = torch.empty(n, dtype=torch.int32, device=node_type.device)
+    if keep_mask is not None:
+        assert keep_mask.dtype == torch.uint8 and keep_mask.shape == (n, n_dim) and keep_mask.is_contiguous()
+    n_mask = 0
+    if mask_rows is not None:
+        mask_rows = mask_rows.view(-1).to(torch.int64).contiguous()
+        n_mask = mask_rows.numel()
+    _check(load().magic_node_code(n, int(n_dim), _dev(node_type), _dev(keep_mask), n_mask, _dev(mask_rows), _dev(code),
+                                  _stream()), "magic_node_code")
+    return code
+
+
+def gat_fwd_coded(struct, H: int, D: int, ci: CodedInput, ee_table, etype_csc, slope: float, bias, prelu_w,
+                  want_pre: bool, out: Optional[torch.Tensor] = None):
+    """``gat_fwd`` for a layer whose input is given as code words: returns (out, pre | None, stat [N,H,2])."""
+    lib = load()
+    from .graph import LIGHT_MAX
+    N, E = struct.num_nodes, struct.num_edges
+    dev = ci.code.device
+    Cc = H * D
+    assert ci.table.shape[1] >= 2 * Cc + 2 * H
+    if out is None:
+        out = torch.empty(N, Cc, dtype=torch.float32, device=dev)
+    assert out.shape == (N, Cc) and out.stride(1) == 1
+    pre = torch.empty(N, Cc, dtype=torch.float32, device=dev) if want_pre else None
+    stat = torch.empty(N, H, 2, dtype=torch.float32, device=dev)
+    plan = make_plan(struct.plan_in, LIGHT_MAX)
+    ws = workspace(lib.magic_gat_fwd_workspace_bytes(E, struct.plan_in.n_chunks, H, D), dev)
+    cs = ci.struct()
+    _check(lib.magic_gat_fwd_coded(N, E, H, D, C.byref(plan), _dev(struct.in_src), C.byref(cs), _dev(ee_table),
+                                   _dev(etype_csc), float(slope), _dev(bias), _dev(prelu_w), _dev(out), out.stride(0),
+                                   _dev(pre), _dev(stat), ws.data_ptr(), ws.numel(), _stream()), "magic_gat_fwd_coded")
+    return out, pre, stat
+
+
+def gat_bwd_coded(struct, H: int, D: int, ci: CodedInput, stat, ee_table, etype_csr, e_dim: int, slope: float, pre,
+                  act_out, prelu_w, d_out, d_pre, d_y, want_bias: bool):
+    """``gat_bwd`` for a coded-input layer.  Returns (d_ee_table, d_bias | None, d_prelu_w | None)."""
+    lib = load()
+    from .graph import LIGHT_MAX
+    N, E = struct.num_nodes, struct.num_edges
+    dev = ci.code.device
+    Cc = H * D
+    d_table = torch.empty(e_dim, H, dtype=torch.float32, device=dev)
+    d_bias = torch.empty(Cc, dtype=torch.float32, device=dev) if want_bias else None
+    d_prelu = torch.empty(1, dtype=torch.float32, device=dev) if prelu_w is not None else None
+    pin = make_plan(struct.plan_in, LIGHT_MAX)
+    pout = make_plan(struct.plan_out, LIGHT_MAX)
+    ws = workspace(lib.magic_gat_bwd_workspace_bytes(N, E, struct.plan_in.n_chunks, struct.plan_out.n_chunks, H, D,
+                                                     max(e_dim, 1)), dev)
+    d_out = _rows(d_out)
+    act_out = _rows(act_out)
+    assert stat.shape == (N, H, 2) and stat.is_contiguous()
+    cs = ci.struct()
+    _check(lib.magic_gat_bwd_coded(N, E, H, D, C.byref(pin), _dev(struct.in_pos), C.byref(pout), _dev(struct.out_dst),
+                                   _dev(struct.out_pos), C.byref(cs), _dev(stat, torch.float32, "stat"), _dev(ee_table),
+                                   _dev(etype_csr), int(e_dim), float(slope), _dev(pre), _dev(act_out),
+                                   act_out.stride(0) if act_out is not None else 0, _dev(prelu_w),
+                                   _dev(d_out, torch.float32, "d_out"), d_out.stride(0), _dev(d_pre), d_pre.stride(0),
+                                   _dev(d_y), d_y.stride(0), _dev(d_table), _dev(d_bias), _dev(d_prelu), ws.data_ptr(),
+                                   ws.numel(), _stream()), "magic_gat_bwd_coded")
+    return d_table, d_bias, d_prelu
+
+
+def coded_weight_grad(ci: CodedInput, d_y: torch.Tensor, w_aug: torch.Tensor):
+    """(dW [M, n_dim], d_token [1, n_dim]) of a coded-input layer from d_y [N, M] and its augmented weight [M, n_dim]."""
+    lib = load()
+    d_y = _rows(d_y)
+    N, M = d_y.shape
+    assert w_aug.shape == (M, ci.n_dim) and w_aug.stride(1) == 1
+    dev = d_y.device
+    dw = torch.empty(M, ci.n_dim, dtype=torch.float32, device=dev)
+    d_token = torch.empty(1, ci.n_dim, dtype=torch.float32, device=dev)
+    ws = workspace(lib.magic_coded_weight_grad_workspace_bytes(M, ci.n_dim), dev)
+    cs = ci.struct()
+    _check(lib.magic_coded_weight_grad(N, M, C.byref(cs), _dev(d_y, torch.float32, "d_y"), d_y.stride(0),
+                                       _dev(w_aug, torch.float32, "w_aug"), w_aug.stride(0), _dev(dw), dw.stride(0),
+                                       _dev(d_token), ws.data_ptr(), ws.numel(), _stream()), "magic_coded_weight_grad")
+    return dw, d_token
 
 
 # ------------------------------------------------------------------------------------- SCE

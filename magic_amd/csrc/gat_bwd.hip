@@ -65,6 +65,7 @@ struct BwdArgs {
     float *ws_deh;    // [n_chunks_out, H]
     float *ws_table;  // [grid_table, e_dim*H]
     int grid_table;
+    CodedIn ci;  // coded layer input (the CODED source sweeps): replaces hs and eh
 };
 
 // ---- node adjoint: d_pre = d_out * PReLU'(pre), column sums (bias gradient), slope gradient ---
@@ -171,9 +172,10 @@ __device__ __forceinline__ float edge_term(const BwdArgs &a, const float *tbl, i
 // node), the next node's own row, the segment bounds of the node after it and the walk-order entry of
 // the one after that are requested as well.  Every address of an iteration is known when it starts.
 // All loads are unconditional (clamped indices); only stores and accumulations are predicated.
-template <int H, int LPH, bool TABLE>
+template <int H, int LPH, bool TABLE, bool CODED>
 __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
     constexpr int G = H * LPH;
+    constexpr int C = G * 4;
     constexpr int NPB = 256 / G;
     constexpr int SB = 4;  // edges per batch (8 for wide rows: fewer resident waves, slower)
     __shared__ float tbl[TABLE ? MAX_E_DIM * H : 1];
@@ -206,8 +208,16 @@ __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
         v[k] = a.out_dst[jj[k]];
         ee[k] = edge_term<H, TABLE>(a, tbl, jj[k], h);
     }
-    float4 hu = ld4_nt(a.hs + (int64_t)u0 * a.ld_hs + g * 4);
-    float ehu = a.eh[(int64_t)u0 * a.ld_s + h];
+    float4 hu;
+    float ehu;
+    if (CODED) {
+        const uint32_t cu = a.ci.code[u0];
+        hu = coded4(a.ci, cu, g * 4);
+        ehu = coded1(a.ci, cu, C + h);
+    } else {
+        hu = ld4_nt(a.hs + (int64_t)u0 * a.ld_hs + g * 4);
+        ehu = a.eh[(int64_t)u0 * a.ld_s + h];
+    }
     float4 acc = f4zero();
     while (i0 < wk.end) {
         const bool light = e0 - b0 <= a.pout.light_max;
@@ -234,8 +244,14 @@ __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
         float nehu = ehu;
         int b2 = 0, e2 = 0, u3 = 0;
         if (last) {
-            nhu = ld4_nt(a.hs + (int64_t)u1 * a.ld_hs + g * 4);
-            nehu = a.eh[(int64_t)u1 * a.ld_s + h];
+            if (CODED) {
+                const uint32_t cu = a.ci.code[u1];
+                nhu = coded4(a.ci, cu, g * 4);
+                nehu = coded1(a.ci, cu, C + h);
+            } else {
+                nhu = ld4_nt(a.hs + (int64_t)u1 * a.ld_hs + g * 4);
+                nehu = a.eh[(int64_t)u1 * a.ld_s + h];
+            }
             b2 = a.pout.ptr[u2], e2 = a.pout.ptr[u2 + 1];
             u3 = node_at(i0 + 3 * stride);
         }
@@ -276,9 +292,9 @@ __global__ __launch_bounds__(256) void k_bwd_src_light(BwdArgs a) {
 // wave-private LDS strip; the row loop takes the destination of edge k with v_readlane (scalar base
 // address) and double-buffers its batches of four rows, so nothing in it waits on anything but the rows
 // themselves.  The ids / types of the NEXT node are requested while this one runs.
-template <bool TABLE>
+template <bool TABLE, bool CODED>
 __global__ __launch_bounds__(256) void k_bwd_src_wave(BwdArgs a) {
-    constexpr int H = 4, LPH = 16, SB = 4;
+    constexpr int H = 4, LPH = 16, SB = 4, C = 256;
     __shared__ float tbl[TABLE ? MAX_E_DIM * H : 1];
     __shared__ __align__(16) float wls[4][64 * H];
     stage_table<H, TABLE>(a, tbl);
@@ -301,8 +317,15 @@ __global__ __launch_bounds__(256) void k_bwd_src_wave(BwdArgs a) {
     int b1 = a.pout.ptr[u1], e1 = a.pout.ptr[u1 + 1];
     int idx = a.out_dst[edge_slot(b0, e0)];
     int ty = TABLE ? a.etype[edge_slot(b0, e0)] : a.out_pos[edge_slot(b0, e0)];  // dense path: the CSC slot of ee
-    float4 hu = ld4_nt(a.hs + (int64_t)u0 * a.ld_hs + lane * 4);
-    float4 eh4 = ld4(a.eh + (int64_t)u0 * a.ld_s);
+    float4 hu, eh4;
+    if (CODED) {
+        const uint32_t cu = a.ci.code[u0];
+        hu = coded4(a.ci, cu, lane * 4);
+        eh4 = coded4(a.ci, cu, C);
+    } else {
+        hu = ld4_nt(a.hs + (int64_t)u0 * a.ld_hs + lane * 4);
+        eh4 = ld4(a.eh + (int64_t)u0 * a.ld_s);
+    }
     while (i0 < wk.end) {
         const int deg = e0 - b0;
         const bool light = deg <= a.pout.light_max;
@@ -324,8 +347,15 @@ __global__ __launch_bounds__(256) void k_bwd_src_wave(BwdArgs a) {
         // 3. requests for the following nodes
         const int nidx = a.out_dst[edge_slot(b1, e1)];
         const int nty = TABLE ? a.etype[edge_slot(b1, e1)] : a.out_pos[edge_slot(b1, e1)];
-        const float4 nhu = ld4_nt(a.hs + (int64_t)u1 * a.ld_hs + lane * 4);
-        const float4 neh4 = ld4(a.eh + (int64_t)u1 * a.ld_s);
+        float4 nhu, neh4;
+        if (CODED) {
+            const uint32_t cu = a.ci.code[u1];
+            nhu = coded4(a.ci, cu, lane * 4);
+            neh4 = coded4(a.ci, cu, C);
+        } else {
+            nhu = ld4_nt(a.hs + (int64_t)u1 * a.ld_hs + lane * 4);
+            neh4 = ld4(a.eh + (int64_t)u1 * a.ld_s);
+        }
         const int b2 = a.pout.ptr[u2], e2 = a.pout.ptr[u2 + 1];
         const int u3 = node_at(i0 + 3 * stride);
         // 4. attention weights of edge `lane`, all heads, into the strip
@@ -379,7 +409,7 @@ __global__ __launch_bounds__(256) void k_bwd_src_wave(BwdArgs a) {
     }
 }
 
-template <int H, int LPH, bool TABLE>
+template <int H, int LPH, bool TABLE, bool CODED>
 __global__ __launch_bounds__(256) void k_bwd_src_heavy1(BwdArgs a) {
     constexpr int G = H * LPH;
     constexpr int NSG = 64 / G;
@@ -393,8 +423,16 @@ __global__ __launch_bounds__(256) void k_bwd_src_heavy1(BwdArgs a) {
     const int beg = a.pout.chunk_beg[c], end = a.pout.chunk_end[c];
     const int g = lane % G, sg = lane / G, h = g / LPH;
     const bool writer = (g % LPH) == 0;
-    const float4 hu = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
-    const float ehu = a.eh[(int64_t)u * a.ld_s + h];
+    float4 hu;
+    float ehu;
+    if (CODED) {
+        const uint32_t cu = a.ci.code[u];
+        hu = coded4(a.ci, cu, g * 4);
+        ehu = coded1(a.ci, cu, C + h);
+    } else {
+        hu = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
+        ehu = a.eh[(int64_t)u * a.ld_s + h];
+    }
     float4 acc = f4zero();
     for (int j = beg + sg; j < end; j += 4 * NSG) {
         float4 r[4];
@@ -766,7 +804,7 @@ int launch_table(BwdArgs &a, hipStream_t stream) {
     return MAGIC_OK;
 }
 
-template <int H, int LPH, bool TABLE>
+template <int H, int LPH, bool TABLE, bool CODED = false>
 int launch_bwd(BwdArgs &a, hipStream_t stream) {
     constexpr int C = H * LPH * 4;
     constexpr int NPB = 256 / (H * LPH);
@@ -782,12 +820,12 @@ int launch_bwd(BwdArgs &a, hipStream_t stream) {
         return st0 != MAGIC_OK ? st0 : launch_status();
     }
     if (H == 4 && LPH == 16)  // 1 KB rows: one wavefront per node
-        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_wave<TABLE>), stride_grid(a.N, 4, 256 * 5), 256, 0, stream, a);  // resident workgroups only: the pipeline fill is paid once per wavefront
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_wave<TABLE, CODED>), stride_grid(a.N, 4, 256 * 5), 256, 0, stream, a);  // resident workgroups only: the pipeline fill is paid once per wavefront
     else
-        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_light<H, LPH, TABLE>), stride_grid(a.N, NPB, 256 * 16), 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_light<H, LPH, TABLE, CODED>), stride_grid(a.N, NPB, 256 * 16), 256, 0, stream, a);
     if (a.pout.n_chunks > 0) {
         const int cgrid = chunk_grid(a.pout.n_chunks);
-        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_heavy1", H, LPH) : "gat_bwd_src_heavy1", (k_bwd_src_heavy1<H, LPH, TABLE>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_heavy1", H, LPH) : "gat_bwd_src_heavy1", (k_bwd_src_heavy1<H, LPH, TABLE, CODED>), cgrid, 256, 0, stream, a);
         MAGIC_LAUNCH("gat_bwd_src_heavy2", (k_bwd_src_heavy2<H, LPH>), a.pout.n_heavy, 256, 0, stream, a);
     }
     MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_dst_light", H, LPH) : "gat_bwd_dst_light", (k_bwd_dst_light<H>), stride_grid(a.N, 256 / DST_W, 256 * 32), 256, 0, stream, a, C);
@@ -832,18 +870,28 @@ size_t magic_gat_bwd_workspace_bytes(int32_t N, int32_t E, int32_t n_chunks_in, 
     return b + 256;
 }
 
-int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_pos,
-                  const magic_plan *out_plan, const int32_t *out_dst, const int32_t *out_pos, const float *hs,
-                  int64_t ld_hs, const float *eh, int64_t ld_score, const float *stat, const float *ee_table,
-                  const int32_t *etype_csr, const float *ee_csc, int32_t e_dim, float slope, const float *pre,
-                  const float *act_out, int64_t ld_act, const float *prelu_w, const float *d_out, int64_t ld_dout,
-                  float *d_pre, int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table, float *d_logit,
-                  float *d_bias, float *d_prelu_w, void *workspace, size_t workspace_bytes, void *stream_) {
+// both entry points: `ci` != NULL selects the coded-input source sweeps (hs and eh are then not read)
+static int gat_bwd_run(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_pos,
+                       const magic_plan *out_plan, const int32_t *out_dst, const int32_t *out_pos, const float *hs,
+                       int64_t ld_hs, const float *eh, int64_t ld_score, const float *stat, const float *ee_table,
+                       const int32_t *etype_csr, const float *ee_csc, int32_t e_dim, float slope, const float *pre,
+                       const float *act_out, int64_t ld_act, const float *prelu_w, const float *d_out, int64_t ld_dout,
+                       float *d_pre, int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table, float *d_logit,
+                       float *d_bias, float *d_prelu_w, void *workspace, size_t workspace_bytes, void *stream_,
+                       const magic_coded_input *ci) {
     using namespace magic;
     if (N < 0 || E < 0 || H <= 0 || D <= 0) return MAGIC_ERR_INVALID_ARG;
     if (!shape_supported(H, D)) return MAGIC_ERR_UNSUPPORTED;
     if (N == 0) return MAGIC_OK;
     const int C = H * D;
+    if (ci) {
+        if (!ci->code || !ci->table || ci->n_dim <= 0 || ci->n_dim > MAGIC_CODED_MAX_DIM) return MAGIC_ERR_INVALID_ARG;
+        if (ci->ld_table < 2 * C + 2 * H || (ci->ld_table & 3) || ((uintptr_t)ci->table & 15)) return MAGIC_ERR_INVALID_ARG;
+        if (H != 4 || !ee_table) return MAGIC_ERR_UNSUPPORTED;
+        hs = eh = d_out;  // (placeholders: never read)
+        ld_hs = ld_dout;
+        ld_score = H;
+    }
     if (!plan_valid(in_plan) || !plan_valid(out_plan) || !hs || !d_out || !d_pre || !d_y) return MAGIC_ERR_INVALID_ARG;
     if (out_plan->light_max > 64) return MAGIC_ERR_UNSUPPORTED;  // lane = edge in the wavefront-per-node sweep
     const bool table = ee_table != nullptr;
@@ -904,12 +952,48 @@ int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     if (!ar.ok()) return MAGIC_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int lph = D / 4;
+    a.ci = CodedIn{nullptr, nullptr, 0, C};
+    if (ci) {
+        a.ci = CodedIn{ci->code, ci->table, (int)ci->ld_table, C};
+        switch (lph) {
+            case 2: return launch_bwd<4, 2, true, true>(a, stream);
+            case 4: return launch_bwd<4, 4, true, true>(a, stream);
+            case 8: return launch_bwd<4, 8, true, true>(a, stream);
+            case 16: return launch_bwd<4, 16, true, true>(a, stream);
+        }
+        return MAGIC_ERR_UNSUPPORTED;
+    }
 #define X(h, l)                                                \
     if (H == h && lph == l)                                    \
         return table ? launch_bwd<h, l, true>(a, stream) : launch_bwd<h, l, false>(a, stream);
     MAGIC_GAT_SHAPES(X)
 #undef X
     return MAGIC_ERR_UNSUPPORTED;
+}
+
+int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_pos,
+                  const magic_plan *out_plan, const int32_t *out_dst, const int32_t *out_pos, const float *hs,
+                  int64_t ld_hs, const float *eh, int64_t ld_score, const float *stat, const float *ee_table,
+                  const int32_t *etype_csr, const float *ee_csc, int32_t e_dim, float slope, const float *pre,
+                  const float *act_out, int64_t ld_act, const float *prelu_w, const float *d_out, int64_t ld_dout,
+                  float *d_pre, int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table, float *d_logit,
+                  float *d_bias, float *d_prelu_w, void *workspace, size_t workspace_bytes, void *stream_) {
+    return gat_bwd_run(N, E, H, D, in_plan, in_pos, out_plan, out_dst, out_pos, hs, ld_hs, eh, ld_score, stat, ee_table,
+                       etype_csr, ee_csc, e_dim, slope, pre, act_out, ld_act, prelu_w, d_out, ld_dout, d_pre, ld_dpre,
+                       d_y, ld_dy, d_ee_table, d_logit, d_bias, d_prelu_w, workspace, workspace_bytes, stream_, nullptr);
+}
+
+int magic_gat_bwd_coded(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_pos,
+                        const magic_plan *out_plan, const int32_t *out_dst, const int32_t *out_pos,
+                        const magic_coded_input *input, const float *stat, const float *ee_table,
+                        const int32_t *etype_csr, int32_t e_dim, float slope, const float *pre, const float *act_out,
+                        int64_t ld_act, const float *prelu_w, const float *d_out, int64_t ld_dout, float *d_pre,
+                        int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table, float *d_bias, float *d_prelu_w,
+                        void *workspace, size_t workspace_bytes, void *stream_) {
+    if (!input) return MAGIC_ERR_INVALID_ARG;
+    return gat_bwd_run(N, E, H, D, in_plan, in_pos, out_plan, out_dst, out_pos, nullptr, 0, nullptr, 0, stat, ee_table,
+                       etype_csr, nullptr, e_dim, slope, pre, act_out, ld_act, prelu_w, d_out, ld_dout, d_pre, ld_dpre,
+                       d_y, ld_dy, d_ee_table, nullptr, d_bias, d_prelu_w, workspace, workspace_bytes, stream_, input);
 }
 
 }  // extern "C"

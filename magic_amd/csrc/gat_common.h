@@ -177,6 +177,31 @@ __device__ __forceinline__ float pack_attn(float a, float x) {
 }
 __device__ __forceinline__ bool attn_neg(float packed) { return (__float_as_uint(packed) >> 31) != 0u; }
 
+// ---- coded layer input ---------------------------------------------------------------------------
+// The first encoder layer's input row is one-hot(node type) or, for a masked node, the mask token, under a
+// dropout keep mask: x[u, j] = keep_j(u) * scale * (masked(u) ? token[j] : [j == type(u)]).  Such a row takes one
+// of n_dim + 1 + 2^n_dim values (a kept type, the dropped row, the token under one of the 2^n_dim keep patterns),
+// so everything the layer derives linearly from it -- its projected row hs[u], its head scores eh[u] / et[u], its
+// linear residual -- is one row of a small table (coded.hip builds it from the transposed augmented weight: 20 KB
+// at n_dim 5, 4.4 MB at n_dim 13).  The sweeps fetch that row by a 4-byte code word per node (the row index)
+// from the caches instead of gathering 4*C-byte rows of a materialised [N, C] array from HBM.
+//   table [rows, ld]: columns [0, C) hs | [C, C+H) eh | [C+H, C+2H) et | [C+2H, 2C+2H) residual.
+struct CodedIn {
+    const uint32_t *code;  // [N] table row of every node
+    const float *tab;      // [rows, ld]
+    int ld;
+    int C;  // width of the hs block (column offsets of the others follow from it and H)
+};
+
+// columns [col, col + 4) of the node's table row (col % 4 == 0)
+__device__ __forceinline__ float4 coded4(const CodedIn &ci, uint32_t code, int col) {
+    return ld4(ci.tab + (size_t)code * ci.ld + col);
+}
+// one column of it
+__device__ __forceinline__ float coded1(const CodedIn &ci, uint32_t code, int col) {
+    return ci.tab[(size_t)code * ci.ld + col];
+}
+
 // dispatch over the compiled (H, LPH) shapes
 #define MAGIC_GAT_SHAPES(X) \
     X(4, 4)                 \

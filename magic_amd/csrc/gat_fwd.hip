@@ -43,6 +43,7 @@ struct FwdArgs {
     float *ws_stats;  // [n_chunks,H,2]
     float *ws_acc;    // [n_chunks * agg_split,C]
     int agg_split;    // waves that share one chunk in the aggregation (graphs with few chunks)
+    CodedIn ci;       // coded layer input (the CODED kernels): replaces hs, eh, et and res
 };
 
 // A chunk is 256 edges, taken four gathered rows at a time by one wave: a graph with few heavy edges leaves
@@ -60,9 +61,23 @@ constexpr int SEG = 64;  // longest segment a lane group takes (the plan's light
 // Raw logit of CSC edge i (source u) under head h: (eh[u] + edge term) + et[v], the sum order of
 // model/gat.py:302-304 (u_add_v after the edge term joined the source score).
 template <int H, bool TABLE>
-__device__ __forceinline__ float edge_logit(const FwdArgs &a, int i, int u, int h, float etv) {
+__device__ __forceinline__ float edge_logit_from(const FwdArgs &a, int i, float ehu, int h, float etv) {
     const float ee = TABLE ? a.ee_table[a.etype[i] * H + h] : a.ee[(int64_t)i * H + h];
-    return (a.eh[(int64_t)u * a.ld_s + h] + ee) + etv;
+    return (ehu + ee) + etv;
+}
+template <int H, bool TABLE>
+__device__ __forceinline__ float edge_logit(const FwdArgs &a, int i, int u, int h, float etv) {
+    return edge_logit_from<H, TABLE>(a, i, a.eh[(int64_t)u * a.ld_s + h], h, etv);
+}
+// the H source scores of a coded node (H == 4: one float4 of the table's eh block)
+template <int H> __device__ __forceinline__ void coded_heads(const CodedIn &ci, uint32_t code, int col0, float (&o)[H]) {
+    if (H == 4) {
+        const float4 q = coded4(ci, code, col0);
+        o[0] = q.x, o[1 % H] = q.y, o[2 % H] = q.z, o[3 % H] = q.w;
+    } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h) o[h] = coded1(ci, code, col0 + h);
+    }
 }
 
 // sum / max over the G (aligned, all active) lanes of a node's group; every lane receives the same bits
@@ -84,11 +99,13 @@ __device__ __forceinline__ float sign_of(float w, float packed) {
     return __uint_as_float(__float_as_uint(w) | (__float_as_uint(packed) & 0x80000000u));
 }
 
-template <int H, int LPH>
+template <int H, int LPH, bool CODED>
 __device__ __forceinline__ void epilogue(const FwdArgs &a, int v, int g, float4 acc) {
     constexpr int C = H * LPH * 4;
     if (a.bias) add4(acc, ld4(a.bias + g * 4));
-    if (a.res) {
+    if (CODED) {  // linear residual of the coded input row (the dropout is part of its coefficients)
+        add4(acc, coded4(a.ci, a.ci.code[v], C + 2 * H + g * 4));
+    } else if (a.res) {
         float4 r = ld4_nt(a.res + (int64_t)v * a.ld_res + g * 4);
         if (a.res_mask) {  // residual input = dropout(input): keep mask applied on the fly
             const uchar4 m = *reinterpret_cast<const uchar4 *>(a.res_mask + (int64_t)v * C + g * 4);
@@ -120,9 +137,10 @@ __device__ __forceinline__ void epilogue(const FwdArgs &a, int v, int g, float4 
 //     source's head scores -> logits into the group's LDS strip; group max; exponentials back into the strip
 //     (sign bit = "logit <= 0"); group sum; then the sub-streams walk the strip (weights by LDS broadcast,
 //     source ids from LDS) for the aggregation.  A logit is computed once.
-template <int H, int LPH, bool TABLE>
+template <int H, int LPH, bool TABLE, bool CODED>
 __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
     constexpr int G = H * LPH;
+    constexpr int C = G * 4;
     constexpr int W = G < 8 ? 8 : G;
     constexpr int NSUB = W / G;
     constexpr int NPB = 256 / W;
@@ -143,7 +161,8 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
         const int b = a.plan.ptr[v], e = a.plan.ptr[v + 1];
         const int deg = e - b;
         if (deg > a.plan.light_max) continue;
-        const float etv = a.et[(int64_t)v * a.ld_s + h];
+        const uint32_t cv = CODED ? a.ci.code[v] : 0u;
+        const float etv = CODED ? coded1(a.ci, cv, C + H + h) : a.et[(int64_t)v * a.ld_s + h];
         float4 acc = f4zero();
         float lse = 0.f;
         if (NSUB == 1 && deg > 0 && deg <= 4) {
@@ -153,8 +172,14 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
             for (int j = 0; j < 4; ++j) {
                 const int ii = min(b + j, e - 1);
                 const int u = a.src[ii];
-                r[j] = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
-                x[j] = edge_logit<H, TABLE>(a, ii, u, h, etv);
+                if (CODED) {
+                    const uint32_t cu = a.ci.code[u];
+                    r[j] = coded4(a.ci, cu, g * 4);
+                    x[j] = edge_logit_from<H, TABLE>(a, ii, coded1(a.ci, cu, C + h), h, etv);
+                } else {
+                    r[j] = ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
+                    x[j] = edge_logit<H, TABLE>(a, ii, u, h, etv);
+                }
                 l[j] = leaky(x[j], a.slope);
             }
             float m = l[0];
@@ -181,9 +206,10 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
             // lane = edge: logits of all heads into the strip, running max per head; two edges per trip so
             // that their id -> score chains overlap
             float et4[H], m4[H], s4[H];
+            if (CODED) coded_heads<H>(a.ci, cv, C + H, et4);
 #pragma unroll
             for (int k = 0; k < H; ++k) {
-                et4[k] = a.et[(int64_t)v * a.ld_s + k];
+                if (!CODED) et4[k] = a.et[(int64_t)v * a.ld_s + k];
                 m4[k] = -INFINITY;
                 s4[k] = 0.f;
             }
@@ -191,12 +217,24 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
             for (int k = t; k < deg; k += 2 * W) {
                 const int k2 = min(k + W, deg - 1);
                 const bool two = k + W < deg;
-                const int u1 = a.src[b + k], u2 = a.src[b + k2];
+                int u1 = a.src[b + k], u2 = a.src[b + k2];
                 float x1[H], x2[H];
+                if (CODED) {  // the strip keeps the code words: the row loop needs nothing else of a source
+                    u1 = (int)a.ci.code[u1], u2 = (int)a.ci.code[u2];
+                    float e1[H], e2[H];
+                    coded_heads<H>(a.ci, (uint32_t)u1, C, e1);
+                    coded_heads<H>(a.ci, (uint32_t)u2, C, e2);
 #pragma unroll
-                for (int hh = 0; hh < H; ++hh) {
-                    x1[hh] = edge_logit<H, TABLE>(a, b + k, u1, hh, et4[hh]);
-                    x2[hh] = edge_logit<H, TABLE>(a, b + k2, u2, hh, et4[hh]);
+                    for (int hh = 0; hh < H; ++hh) {
+                        x1[hh] = edge_logit_from<H, TABLE>(a, b + k, e1[hh], hh, et4[hh]);
+                        x2[hh] = edge_logit_from<H, TABLE>(a, b + k2, e2[hh], hh, et4[hh]);
+                    }
+                } else {
+#pragma unroll
+                    for (int hh = 0; hh < H; ++hh) {
+                        x1[hh] = edge_logit<H, TABLE>(a, b + k, u1, hh, et4[hh]);
+                        x2[hh] = edge_logit<H, TABLE>(a, b + k2, u2, hh, et4[hh]);
+                    }
                 }
                 us[k] = u1;
 #pragma unroll
@@ -242,7 +280,7 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int kk = min(k + j * NSUB, deg - 1);
-                    r[j] = ld4(a.hs + (int64_t)us[kk] * a.ld_hs + g * 4);
+                    r[j] = CODED ? coded4(a.ci, (uint32_t)us[kk], g * 4) : ld4(a.hs + (int64_t)us[kk] * a.ld_hs + g * 4);
                     pw[j] = ws[kk * H + h];
                 }
 #pragma unroll
@@ -267,14 +305,14 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
         if (sub == 0) {
             if (writer && a.stat)
                 *reinterpret_cast<float2 *>(a.stat + ((int64_t)v * H + h) * 2) = make_float2(etv, lse);
-            epilogue<H, LPH>(a, v, g, acc);
+            epilogue<H, LPH, CODED>(a, v, g, acc);
         }
     }
 }
 
 // Heavy segments, step 1: one wave per chunk, one lane per edge; forms the logits of the chunk's edges
 // (kept in x for step 2) and the per-chunk (max, sum exp) of every head.
-template <int H, bool TABLE>
+template <int H, bool TABLE, bool CODED>
 __global__ __launch_bounds__(256) void k_fwd_heavy_stats(FwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int c = xcd_chunk(threadIdx.x >> 6);
@@ -282,11 +320,12 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_stats(FwdArgs a) {
     const int beg = a.plan.chunk_beg[c], end = a.plan.chunk_end[c];
     const int v = a.plan.heavy_node[a.plan.chunk_node[c]];
     float m[H], s[H], etv[H];
+    if (CODED) coded_heads<H>(a.ci, a.ci.code[v], a.ci.C + H, etv);
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         m[h] = -INFINITY;
         s[h] = 0.f;
-        etv[h] = a.et[(int64_t)v * a.ld_s + h];
+        if (!CODED) etv[h] = a.et[(int64_t)v * a.ld_s + h];
     }
     for (int i0 = beg + lane; i0 < end; i0 += 256) {  // four edges per lane and trip: their id -> score chains overlap
         int ii[4], u[4];
@@ -297,9 +336,17 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_stats(FwdArgs a) {
             u[j] = a.src[ii[j]];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            if (CODED) {
+                float eh[H];
+                coded_heads<H>(a.ci, a.ci.code[u[j]], a.ci.C, eh);
 #pragma unroll
-            for (int h = 0; h < H; ++h) x[j][h] = edge_logit<H, TABLE>(a, ii[j], u[j], h, etv[h]);
+                for (int h = 0; h < H; ++h) x[j][h] = edge_logit_from<H, TABLE>(a, ii[j], eh[h], h, etv[h]);
+            } else {
+#pragma unroll
+                for (int h = 0; h < H; ++h) x[j][h] = edge_logit<H, TABLE>(a, ii[j], u[j], h, etv[h]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (i0 + 64 * j < end) {
@@ -352,7 +399,7 @@ __device__ __forceinline__ void node_stats(const FwdArgs &a, int slot, int lane,
 
 // Heavy segments, step 2: one wave per chunk; the 64/G lane groups take edges round robin,
 // write the attention weights and a partial aggregate per chunk.
-template <int H, int LPH>
+template <int H, int LPH, bool CODED>
 __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
     constexpr int G = H * LPH;
     constexpr int NSG = 64 / G;
@@ -382,8 +429,8 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
     const bool writer = (g % LPH) == 0;
     if (a.stat && c == a.plan.heavy_cptr[slot] && run == 0 && sg == 0 && writer) {  // the node's first chunk records its statistics
         const int v = a.plan.heavy_node[slot];
-        *reinterpret_cast<float2 *>(a.stat + ((int64_t)v * H + h) * 2) =
-            make_float2(a.et[(int64_t)v * a.ld_s + h], m + logf(s));
+        const float etv = CODED ? coded1(a.ci, a.ci.code[v], C + H + h) : a.et[(int64_t)v * a.ld_s + h];
+        *reinterpret_cast<float2 *>(a.stat + ((int64_t)v * H + h) * 2) = make_float2(etv, m + logf(s));
     }
     float4 acc = f4zero();
     int i = beg + sg;
@@ -391,7 +438,10 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
         float4 r[4];
         float w[4], x[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = ld4(a.hs + (int64_t)a.src[i + j * NSG] * a.ld_hs + g * 4);
+        for (int j = 0; j < 4; ++j) {
+            const int u = a.src[i + j * NSG];
+            r[j] = CODED ? coded4(a.ci, a.ci.code[u], g * 4) : ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) x[j] = a.x[(int64_t)(i + j * NSG) * H + h];
 #pragma unroll
@@ -403,7 +453,8 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
         for (int j = 0; j < 4; ++j) fma4(acc, w[j], r[j]);
     }
     for (; i < end; i += NSG) {
-        float4 r = ld4(a.hs + (int64_t)a.src[i] * a.ld_hs + g * 4);
+        const int u = a.src[i];
+        float4 r = CODED ? coded4(a.ci, a.ci.code[u], g * 4) : ld4(a.hs + (int64_t)u * a.ld_hs + g * 4);
         float x = a.x[(int64_t)i * H + h];
         float w = __expf(leaky(x, a.slope) - m) * inv;
         if (writer && a.attn) a.attn[(int64_t)i * H + h] = pack_attn(w, x);
@@ -415,7 +466,7 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
 
 // Heavy segments, step 3: one block per heavy node sums its chunk partials in a fixed order
 // (sub-groups take chunks round robin, LDS tree in sub-group order) and applies the epilogue.
-template <int H, int LPH>
+template <int H, int LPH, bool CODED>
 __global__ __launch_bounds__(256) void k_fwd_heavy_finish(FwdArgs a) {
     constexpr int G = H * LPH;
     constexpr int NSGB = 256 / G;
@@ -430,24 +481,24 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_finish(FwdArgs a) {
     __syncthreads();
     if (sg == 0) {
         for (int k = 1; k < NSGB; ++k) add4(acc, part[k * G + g]);
-        epilogue<H, LPH>(a, a.plan.heavy_node[slot], g, acc);
+        epilogue<H, LPH, CODED>(a, a.plan.heavy_node[slot], g, acc);
     }
 }
 
-template <int H, int LPH, bool TABLE>
+template <int H, int LPH, bool TABLE, bool CODED = false>
 int launch_fwd(const FwdArgs &a, hipStream_t stream) {
     constexpr int G = H * LPH;
     constexpr int NPB = 256 / (G < 8 ? 8 : G);
     if (a.N > 0) {
         int grid = stride_grid(a.N, NPB, 256 * 32);
-        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_light", H, LPH) : "gat_fwd_light", (k_fwd_light<H, LPH, TABLE>), grid, 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_light", H, LPH) : "gat_fwd_light", (k_fwd_light<H, LPH, TABLE, CODED>), grid, 256, 0, stream, a);
     }
     if (a.plan.n_chunks > 0) {
         int cgrid = chunk_grid(a.plan.n_chunks);
-        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_heavy_stats", H, LPH) : "gat_fwd_heavy_stats", (k_fwd_heavy_stats<H, TABLE>), cgrid, 256, 0, stream, a);
-        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_heavy_agg", H, LPH) : "gat_fwd_heavy_agg", (k_fwd_heavy_agg<H, LPH>),
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_heavy_stats", H, LPH) : "gat_fwd_heavy_stats", (k_fwd_heavy_stats<H, TABLE, CODED>), cgrid, 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_heavy_agg", H, LPH) : "gat_fwd_heavy_agg", (k_fwd_heavy_agg<H, LPH, CODED>),
                      chunk_grid(a.plan.n_chunks * a.agg_split), 256, 0, stream, a);
-        MAGIC_LAUNCH("gat_fwd_heavy_finish", (k_fwd_heavy_finish<H, LPH>), a.plan.n_heavy, 256, 0, stream, a);
+        MAGIC_LAUNCH("gat_fwd_heavy_finish", (k_fwd_heavy_finish<H, LPH, CODED>), a.plan.n_heavy, 256, 0, stream, a);
     }
     return launch_status();
 }
@@ -464,18 +515,29 @@ size_t magic_gat_fwd_workspace_bytes(int32_t n_edges, int32_t n_chunks, int32_t 
     return b + 256;
 }
 
-int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_src,
-                  const int32_t *in_dst, const float *hs, int64_t ld_hs, const float *eh, const float *et,
-                  int64_t ld_score, const float *ee_table, const int32_t *etype_csc, const float *ee_csc,
-                  float slope, const float *bias, const float *res, int64_t ld_res, const uint8_t *res_mask,
-                  float res_scale, const float *prelu_w,
-                  float *out, int64_t ld_out, float *pre, float *attn, float *stat, void *workspace,
-                  size_t workspace_bytes, void *stream_) {
+// both entry points: `ci` != NULL selects the coded-input kernels (hs, eh, et and res are then not read)
+static int gat_fwd_run(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_src,
+                       const int32_t *in_dst, const float *hs, int64_t ld_hs, const float *eh, const float *et,
+                       int64_t ld_score, const float *ee_table, const int32_t *etype_csc, const float *ee_csc,
+                       float slope, const float *bias, const float *res, int64_t ld_res, const uint8_t *res_mask,
+                       float res_scale, const float *prelu_w, float *out, int64_t ld_out, float *pre, float *attn,
+                       float *stat, void *workspace, size_t workspace_bytes, void *stream_,
+                       const magic_coded_input *ci) {
     using namespace magic;
     if (N < 0 || E < 0 || H <= 0 || D <= 0) return MAGIC_ERR_INVALID_ARG;
     if (!shape_supported(H, D)) return MAGIC_ERR_UNSUPPORTED;
     if (N == 0) return MAGIC_OK;
-    if (!plan_valid(in_plan) || !hs || !eh || !et || !out) return MAGIC_ERR_INVALID_ARG;
+    if (!plan_valid(in_plan) || !out) return MAGIC_ERR_INVALID_ARG;
+    if (ci) {
+        if (!ci->code || !ci->table || ci->n_dim <= 0 || ci->n_dim > MAGIC_CODED_MAX_DIM) return MAGIC_ERR_INVALID_ARG;
+        if (ci->ld_table < 2 * H * D + 2 * H || (ci->ld_table & 3) || ((uintptr_t)ci->table & 15)) return MAGIC_ERR_INVALID_ARG;
+        if (H != 4 || !ee_table) return MAGIC_ERR_UNSUPPORTED;  // compiled for the encoder's four heads, typed edges
+        hs = eh = et = out;  // (placeholders: never read)
+        ld_hs = ld_out;
+        ld_score = H;
+        res = nullptr;
+    }
+    if (!hs || !eh || !et) return MAGIC_ERR_INVALID_ARG;
     if (E > 0 && !in_src) return MAGIC_ERR_INVALID_ARG;
     if (in_plan->light_max > magic::SEG) return MAGIC_ERR_UNSUPPORTED;  // a lane group's strip holds SEG edges
     const bool table = ee_table != nullptr;
@@ -512,6 +574,8 @@ int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     a.stat = stat;
     a.ws_stats = a.ws_acc = nullptr;
     a.agg_split = agg_split_for(a.plan.n_chunks);
+    a.ci = CodedIn{nullptr, nullptr, 0, C};
+    if (ci) a.ci = CodedIn{ci->code, ci->table, (int)ci->ld_table, C};
     Arena ar(workspace, workspace_bytes);
     a.x = ar.take<float>((size_t)(E > 0 ? E : 1) * H);
     if (a.plan.n_chunks > 0) {
@@ -521,11 +585,42 @@ int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
     if (!ar.ok() || !a.x) return MAGIC_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int lph = D / 4;
+    if (ci) {
+        switch (lph) {
+            case 2: return launch_fwd<4, 2, true, true>(a, stream);
+            case 4: return launch_fwd<4, 4, true, true>(a, stream);
+            case 8: return launch_fwd<4, 8, true, true>(a, stream);
+            case 16: return launch_fwd<4, 16, true, true>(a, stream);
+        }
+        return MAGIC_ERR_UNSUPPORTED;
+    }
 #define X(h, l) \
     if (H == h && lph == l) return table ? launch_fwd<h, l, true>(a, stream) : launch_fwd<h, l, false>(a, stream);
     MAGIC_GAT_SHAPES(X)
 #undef X
     return MAGIC_ERR_UNSUPPORTED;
+}
+
+int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_src,
+                  const int32_t *in_dst, const float *hs, int64_t ld_hs, const float *eh, const float *et,
+                  int64_t ld_score, const float *ee_table, const int32_t *etype_csc, const float *ee_csc,
+                  float slope, const float *bias, const float *res, int64_t ld_res, const uint8_t *res_mask,
+                  float res_scale, const float *prelu_w,
+                  float *out, int64_t ld_out, float *pre, float *attn, float *stat, void *workspace,
+                  size_t workspace_bytes, void *stream_) {
+    return gat_fwd_run(N, E, H, D, in_plan, in_src, in_dst, hs, ld_hs, eh, et, ld_score, ee_table, etype_csc, ee_csc,
+                       slope, bias, res, ld_res, res_mask, res_scale, prelu_w, out, ld_out, pre, attn, stat, workspace,
+                       workspace_bytes, stream_, nullptr);
+}
+
+int magic_gat_fwd_coded(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_src,
+                        const magic_coded_input *input, const float *ee_table, const int32_t *etype_csc, float slope,
+                        const float *bias, const float *prelu_w, float *out, int64_t ld_out, float *pre, float *stat,
+                        void *workspace, size_t workspace_bytes, void *stream_) {
+    if (!input) return MAGIC_ERR_INVALID_ARG;
+    return gat_fwd_run(N, E, H, D, in_plan, in_src, nullptr, nullptr, 0, nullptr, nullptr, 0, ee_table, etype_csc,
+                       nullptr, slope, bias, nullptr, 0, nullptr, 1.f, prelu_w, out, ld_out, pre, nullptr, stat,
+                       workspace, workspace_bytes, stream_, input);
 }
 
 }  // extern "C"

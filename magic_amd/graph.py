@@ -234,6 +234,8 @@ class Graph:
         self._cache: Dict[str, tuple] = {}
         # identity of an edata['attr'] tensor known by construction to be one_hot(edata['type'])
         self._onehot_edge: Optional[tuple] = None
+        # the same for ndata['attr'] / ndata['type']
+        self._onehot_node: Optional[tuple] = None
 
     # DGL aliases: srcdata/dstdata are ndata on a homogeneous graph
     @property
@@ -287,6 +289,7 @@ class Graph:
         g._batch_num_edges = None if self._batch_num_edges is None else list(self._batch_num_edges)
         g._cache = self._cache  # entries are keyed by the identity of the column tensors clones share
         g._onehot_edge = self._onehot_edge
+        g._onehot_node = self._onehot_node
         return g
 
     def to(self, device) -> "Graph":
@@ -301,6 +304,8 @@ class Graph:
         g._batch_num_nodes, g._batch_num_edges = self._batch_num_nodes, self._batch_num_edges
         if self._edge_attr_marked():      # the moved attr is a copy of a tensor known to be one_hot(type)
             g.mark_edge_attr_onehot()
+        if self._node_attr_marked():
+            g.mark_node_attr_onehot()
         return g
 
     @contextlib.contextmanager
@@ -324,6 +329,24 @@ class Graph:
         back to the host.  The mark dies with any later write to, or rebinding of, the tensor."""
         attr = self.edata["attr"]
         self._onehot_edge = (weakref.ref(attr), attr._version)
+
+    def _node_attr_marked(self) -> bool:
+        m, attr = self._onehot_node, self.ndata.get("attr")
+        return m is not None and attr is not None and m[0]() is attr and m[1] == attr._version
+
+    def mark_node_attr_onehot(self):
+        """Declare that ``ndata['attr']`` was just built as ``one_hot(ndata['type'])``
+        (``utils/loaddata.py:258``).  The mark dies with any later write to, or rebinding of, the tensor
+        (the masking step's token write included: it is read before that write)."""
+        attr = self.ndata["attr"]
+        self._onehot_node = (weakref.ref(attr), attr._version)
+
+    def node_types_if_onehot(self) -> Optional[torch.Tensor]:
+        """``ndata['type']`` (int64 [N]) while ``ndata['attr']`` is known to be its one-hot, else None."""
+        t = self.ndata.get("type")
+        if t is None or not self._node_attr_marked() or t.numel() != self.num_nodes():
+            return None
+        return t.view(-1)
 
     # ---- helpers used by the HIP operators -------------------------------------------
     def edge_types_csc(self) -> Optional[torch.Tensor]:
@@ -565,6 +588,8 @@ def batch(graphs: Sequence[Graph]) -> Graph:
             out.edata[k] = torch.cat([g.edata[k] for g in graphs], 0)
     if "attr" in out.edata and "type" in out.edata and all(g._edge_attr_marked() for g in graphs):
         out.mark_edge_attr_onehot()
+    if "attr" in out.ndata and "type" in out.ndata and all(g._node_attr_marked() for g in graphs):
+        out.mark_node_attr_onehot()
     out._batch_num_nodes = [g.num_nodes() for g in graphs]
     out._batch_num_edges = [g.num_edges() for g in graphs]
     assert dev == out.device

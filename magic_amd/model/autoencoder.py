@@ -18,6 +18,8 @@ import random
 from functools import partial
 from itertools import chain
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -133,6 +135,9 @@ class GMAEModel(nn.Module):
                  residual, norm, mask_rate=0.5, loss_fn="sce", alpha_l=2, mask_rng="cpu", alias_clone=True):
         super().__init__()
         self.alias_clone = alias_clone
+        # run the first encoder layer on code words (node type, masked, dropout bits) when the input is known to
+        # be one-hot node types; MAGIC_CODED_INPUT=0 (or this attribute) keeps the dense projection instead
+        self.coded_input = os.environ.get("MAGIC_CODED_INPUT", "1") != "0"
         self._mask_rate = mask_rate
         self._output_hidden_size = hidden_dim
         self._alpha_l = alpha_l
@@ -283,6 +288,8 @@ class GMAEModel(nn.Module):
         ``neg_valid`` (bool mask) marks which of the injected ``neg_pairs`` count (the rest get weight 0
         in the BCE, as the candidates this method draws itself); ``drop_seeds``: see ``_dropout_masks``."""
         feat_has_grad = g.ndata["attr"].requires_grad
+        # (read before the masking step writes the token into the attribute tensor)
+        node_types = g.node_types_if_onehot() if self.coded_input else None
         pre_use_g, (mask_nodes, keep_nodes) = self.encoding_mask_noise(g, self._mask_rate, perm)
         pre_use_x = pre_use_g.ndata["attr"].to(pre_use_g.device)
         use_g = pre_use_g
@@ -326,6 +333,7 @@ class GMAEModel(nn.Module):
                 # the features' only differentiable content is the token written into the masked
                 # rows: hand the chain the plain values and let it return the token's gradient
                 cfg.token_rows = mask_nodes
+                cfg.node_types = node_types      # one-hot input: the first layer runs on code words
                 enc_rep, recon_p, samples = FusedGMAEFn.apply(pre_use_x.detach(), sample_idx, cfg,
                                                               self.enc_mask_token, *params)
             recon = recon_p[:, :cfg.n_dim]

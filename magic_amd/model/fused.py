@@ -34,7 +34,7 @@ class FusedCfg:
 
     def __init__(self, struct, etype_csc, etype_csr, e_dim, n_layers, n_heads, head_dim, n_dim, dec_dim_pad, slope,
                  res_kinds, masks: List[Optional[torch.Tensor]], drop_scale: float,
-                 token_rows: Optional[torch.Tensor] = None):
+                 token_rows: Optional[torch.Tensor] = None, node_types: Optional[torch.Tensor] = None):
         # edge types in CSC order (forward sweep) and in CSR order (backward sweeps)
         self.struct, self.etype, self.etype_csr, self.e_dim = struct, etype_csc, etype_csr, e_dim
         self.L, self.H, self.D, self.C = n_layers, n_heads, head_dim, n_heads * head_dim
@@ -46,6 +46,15 @@ class FusedCfg:
         # rows of x that hold the (learnable) mask token: with them given, the token's gradient is
         # produced directly and the input gradient is never materialised
         self.token_rows = token_rows
+        # node types [N] when the layer-0 input is known to be one_hot(type) outside the token rows: the first
+        # layer then runs on code words (type, masked, dropout keep bits) and a [n_dim, M] table instead of a
+        # projected [N, C] array -- no projection launch, no gathers of 4C-byte rows, no [N, n_dim] operand
+        self.node_types = node_types
+
+    def coded(self, token) -> bool:
+        return (self.node_types is not None and token is not None and self.res_kinds[0] == "linear" and self.H == 4
+                and self.L >= 2
+                and self.n_dim <= _lib.CODED_MAX_DIM and self.D in (8, 16, 32, 64))
 
 
 def _aligned_rows(n, cols, device):
@@ -70,16 +79,28 @@ class FusedGMAEFn(torch.autograd.Function):
         inp = x if x.stride(-1) == 1 else x.contiguous()
         x_in = inp
         saved = []
+        coded = cfg.coded(token)
         for l in range(L):
             w_aug, table, bias, prelu_w = params[4 * l:4 * l + 4]
             mask = cfg.masks[l]
             kind = cfg.res_kinds[l]
+            out_l = enc[:, l * C:(l + 1) * C]
+            if l == 0 and coded:
+                # every value the projected input row can take, and the row each node maps to
+                scale0 = cfg.scale if mask is not None else 1.0
+                tab = _lib.coded_table(w_aug, token, scale0)
+                code = _lib.node_code(cfg.node_types, cfg.n_dim, mask, cfg.token_rows)
+                ci = _lib.CodedInput(code, tab, token, cfg.n_dim, scale0)
+                _, pre, stat = _lib.gat_fwd_coded(s, H, D, ci, table.contiguous(), cfg.etype, cfg.slope, bias, prelu_w,
+                                                  True, out=out_l)
+                saved += [code, tab, stat, pre]
+                inp = out_l
+                continue
             hs, score, res = ops.proj_fwd(inp, w_aug, C, 2 * H, C if kind == "linear" else 0,
                                            x_mask=mask, x_scale=cfg.scale)
             res_mask = None
             if kind == "identity":
                 res, res_mask = inp, mask
-            out_l = enc[:, l * C:(l + 1) * C]
             _, pre, _, stat = ops.gat_fwd(s, H, D, hs, score[:, :H], score[:, H:], table.contiguous(), cfg.etype,
                                           None, cfg.slope, bias, res, prelu_w, True, res_mask=res_mask,
                                           res_scale=cfg.scale, out=out_l, want_attn=False, want_stat=True)
@@ -95,6 +116,8 @@ class FusedGMAEFn(torch.autograd.Function):
                                           want_stat=True)
         samples = enc[sample_idx]
         ctx.cfg = cfg
+        ctx.coded = coded
+        ctx.token = token.detach() if coded else None
         ctx.set_materialize_grads(False)  # no zero-filled [N, L*C] gradient for the hidden buffer
         ctx.save_for_backward(x_in, sample_idx, enc, rep, hs_d, score_d, stat_d, *saved, *params)
         ctx.mark_non_differentiable(enc)
@@ -149,6 +172,17 @@ class FusedGMAEFn(torch.autograd.Function):
             kind = cfg.res_kinds[l]
             mask = cfg.masks[l]
             inp = x_in if l == 0 else enc[:, (l - 1) * C:l * C]
+            if l == 0 and ctx.coded:
+                # hs / score hold the code words and the table here
+                ci = _lib.CodedInput(hs, score, ctx.token, cfg.n_dim, cfg.scale if mask is not None else 1.0)
+                d_y = d_y_next      # (its residual columns hold d_pre, finished by layer 1's input-gradient epilogue)
+                d_table = _lib.gat_bwd_coded(s, H, D, ci, stat, table, cfg.etype_csr, cfg.e_dim, cfg.slope, None,
+                                             None, None, d_pre, d_pre, d_y, False)[0]
+                grads[0], d_token = _lib.coded_weight_grad(ci, d_y, w_aug)
+                grads[1] = d_table
+                grads[2] = bias_grad
+                grads[3] = prelu_grad.view_as(prelu_w)
+                break
             if l == L - 1:
                 # gradient arrives only through the hidden-state concatenation: the destination
                 # sweep applies the PReLU adjoint and sums the bias / slope gradients itself

@@ -103,6 +103,7 @@ class CapturedTrainStep:
         input buffers of the recorded step."""
         g, m = self.g, self.model
         g.ndata["attr"] = _one_hot_float(self.ntype, self.n_dim)
+        g.mark_node_attr_onehot()
         if inputs is None:
             inputs = dict(perm=self.perm, pos_idx=self.pos, neg_pairs=(self.neg_u, self.neg_v),
                           neg_valid=self.neg_ok, drop_seeds=self.seeds)

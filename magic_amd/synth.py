@@ -74,6 +74,7 @@ def make_graph(n: int, e: int, n_dim: int, e_dim: int, seed: int, device="cpu", 
     if attrs:
         g.ndata["attr"] = torch.nn.functional.one_hot(g.ndata["type"], n_dim).float()
         g.edata["attr"] = torch.nn.functional.one_hot(g.edata["type"], e_dim).float()
+        g.mark_node_attr_onehot()
     return g.to(device) if str(device) != "cpu" else g
 
 

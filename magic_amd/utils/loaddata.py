@@ -106,6 +106,7 @@ def transform_graph(g: Graph, node_feature_dim: int, edge_feature_dim: int) -> G
     new_g.ndata["attr"] = _one_hot_float(g.ndata["type"], node_feature_dim)
     new_g.edata["attr"] = _edge_one_hot(g, edge_feature_dim)
     new_g.mark_edge_attr_onehot()
+    new_g.mark_node_attr_onehot()
     return new_g
 
 

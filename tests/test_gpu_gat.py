@@ -241,6 +241,52 @@ def test_fused_chain_matches_layer_path_and_is_reproducible(cuda):
         assert rel_err(a, b) < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(5, 17, 64, 3), (13, 9, 256, 2), (8, 4, 128, 2), (11, 5, 32, 2)])
+def test_coded_first_layer_equals_dense_projection(cuda, shape):
+    """One-hot node types in, the first encoder layer either on code words + a [n_dim, M] table (no projection
+    launch, no [N, C] operand) or on the dense projection of the materialised one-hot matrix: same loss, hidden
+    states and gradients to rounding, with dropout masks and a non-zero mask token; the coded path must really be
+    the one that ran (its kernels show up in the library's launch log) and is bitwise reproducible."""
+    from magic_amd import _lib
+    n_dim, e_dim, hidden, layers = shape
+    n, e = 900, 5000
+    src, dst, ntype, etype = small_graph(n, e, n_dim, e_dim, seed=31, hub_deg=300, hub_out=200)
+    _, mine = _model_pair(n_dim, e_dim, hidden, layers, cuda)
+    mine.train()
+    gen = torch.Generator().manual_seed(2)
+    widths = [n_dim] + [hidden] * (layers - 1) + [hidden]
+    drop = [(torch.rand(n, w, generator=gen) < 0.9).to(cuda) for w in widths]
+    perm = torch.randperm(n, generator=gen).to(cuda)
+    pos_idx = torch.randperm(src.size, generator=gen)[:n]
+    neg = (torch.randint(0, n, (n,), generator=gen), torch.randint(0, n, (n,), generator=gen))
+    outs = []
+    for coded in (True, True, False):
+        mine.coded_input = coded
+        g = to_graph(src, dst, n, ntype, etype, n_dim, e_dim, cuda)
+        mine.zero_grad(set_to_none=True)
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        loss, parts = mine.compute_loss(g, perm=perm, pos_idx=pos_idx, neg_pairs=neg, drop_masks=drop, return_parts=True)
+        loss.backward()
+        _lib.prof_enable(False)
+        names = set(_lib.prof_read(160))
+        _lib.prof_reset()
+        assert ("node_code" in names) == coded and ("coded_dw_partial" in names) == coded, names
+        outs.append((loss.detach().clone(), [h.detach().clone() for h in parts["hidden"]],
+                     {k: p.grad.clone() for k, p in mine.named_parameters() if p.grad is not None}))
+    mine.coded_input = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+    assert abs(float(outs[0][0]) - float(outs[2][0])) < 1e-5 * abs(float(outs[2][0]))
+    for a, b in zip(outs[0][1], outs[2][1]):
+        assert rel_err(a, b) < 1e-5 and row_rel_err(a, b) < 1e-4
+    assert set(outs[0][2]) == set(outs[2][2])
+    for k in outs[0][2]:
+        assert rel_err(outs[0][2][k], outs[2][2][k]) < 1e-4, k
+    assert float(outs[0][2]["enc_mask_token"].abs().max()) > 0.0
+
+
 def test_embed_matches_oracle_and_is_deterministic(cuda):
     n_dim, e_dim = 11, 23
     n, e = 900, 2600

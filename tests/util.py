@@ -48,6 +48,7 @@ def to_graph(src, dst, n, ntype, etype, n_dim, e_dim, device):
     g.edata["type"] = torch.from_numpy(etype)
     g.ndata["attr"] = torch.nn.functional.one_hot(g.ndata["type"], n_dim).float()
     g.edata["attr"] = torch.nn.functional.one_hot(g.edata["type"], e_dim).float()
+    g.mark_node_attr_onehot()           # (what the loaders' transform_graph does: the coded first layer needs it)
     return g.to(device)
 
 
