@@ -522,10 +522,13 @@ def main():
             configs[key] = gat_leg(args, wl, max(args.steps, 10), max(args.warmup, 3), world, rank, dev, detail=False)
             torch.cuda.empty_cache()
 
-    # ---- KNN leg
+    # ---- KNN leg (and, on one GPU, the embedding extraction that feeds it in the reference's eval.py)
     knn = None
     if not args.no_knn:
         knn = knn_leg(args, world, rank, dev)
+        if world == 1 and rank == 0:
+            torch.cuda.empty_cache()
+            knn["embed"] = embed_leg(args, dev)
 
     # ---- CPU baselines (rank 0, N=1 only)
     cpu_baseline = None
@@ -609,7 +612,7 @@ def compact_line(args, world, leg, entity, knn, configs, cpu_baseline, rows_path
         k = {key: knn[key] for key in ("metric", "value", "unit", "ms_per_step", "dtype", "steps") if key in knn}
         k["workload"] = knn["config"]["short"]
         k["roofline"] = _roof(knn.get("roofline"))
-        for extra in ("cadets",):
+        for extra in ("cadets", "embed"):
             if knn.get(extra):
                 k[extra] = knn[extra]
         cb = knn.get("cpu_baseline")
@@ -622,6 +625,28 @@ def compact_line(args, world, leg, entity, knn, configs, cpu_baseline, rows_path
                           for key, c in configs.items()}
     out["rows_file"] = rows_path
     return out
+
+
+def embed_leg(args, dev):
+    """First half of the E3-Trace configuration: embedding extraction (``model/autoencoder.py:269-282`` under
+    ``eval.py:80-97``): the encoder alone, eval mode, on one E3-Trace-sized train graph with one-hot node types."""
+    from magic_amd import synth
+    from magic_amd.model.autoencoder import GMAEModel
+    from magic_amd.utils.utils import set_random_seed
+    n, e, n_dim, e_dim, hidden, layers = synth.SHAPES["trace"]
+    n, e = max(64, int(n * args.scale)), max(64, int(e * args.scale))
+    set_random_seed(0)
+    model = GMAEModel(n_dim, e_dim, hidden, layers, 4, "prelu", 0.1, 0.2, True, "BatchNorm", 0.5, "sce", 3).to(dev).eval()
+    g = synth.make_graph(n, e, n_dim, e_dim, seed=1005).to(dev)
+    g.structure.ensure_csr()
+    with torch.no_grad():
+        for _ in range(3):
+            emb = model.embed(g)
+        assert emb.shape == (n, hidden)
+        reps = max(args.steps, 10)
+        dt = timed(lambda _i: model.embed(g), reps, 1)
+    return {"ms_per_graph": round(dt / reps * 1e3, 4), "nodes_per_s": round(n * reps / dt, 1),
+            "workload": f"embed() of one E3-Trace-sized graph: N={n} E={g.num_edges()} n_dim={n_dim} hidden={hidden} layers={layers}"}
 
 
 def knn_leg(args, world, rank, dev, k=10):

@@ -377,7 +377,7 @@ class GMAEModel(nn.Module):
     def embed(self, g: Graph):
         """``model/autoencoder.py:269-282``."""
         x = g.ndata["attr"].to(g.device)
-        return self.encoder(g, x)
+        return self.encoder(g, x, node_types=g.node_types_if_onehot() if self.coded_input else None)
 
     @property
     def enc_params(self):

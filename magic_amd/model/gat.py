@@ -289,6 +289,31 @@ class GATConv(nn.Module):
         prelu_w = self.activation.weight if isinstance(self.activation, nn.PReLU) else None
         return w_aug, table, bias, prelu_w
 
+    def onehot_input_ok(self, graph: Graph) -> bool:
+        """True when ``forward_onehot`` serves this layer: inference (no autograd, dropout inactive), the encoder's
+        four heads with a linear residual and a fused PReLU, typed edges, at most 13 input columns."""
+        return (not torch.is_grad_enabled() and (not self.training or self.feat_drop.p == 0.0)
+                and self.n_heads == 4 and _pad_head_dim(self.out_feat) == self.out_feat
+                and self.out_feat in (8, 16, 32, 64) and isinstance(self.res_fc, nn.Linear)
+                and isinstance(self.activation, nn.PReLU) and self.activation.weight.numel() == 1
+                and self.norm is None and self.concat_out and self.bias is not None
+                and self.src_feat <= _lib.CODED_MAX_DIM and graph.edge_types_csc() is not None)
+
+    def forward_onehot(self, graph: Graph, node_types: torch.Tensor):
+        """``forward(graph, one_hot(node_types))`` without the one-hot matrix, the projection launch or the
+        projected [N, C] array: the layer's row of a node is a row of the [n_dim + ..., M] table of its augmented
+        weight, fetched by the node's type inside the sweep (``csrc/coded.hip``).  Inference only."""
+        H, D = self.n_heads, self.out_feat
+        struct = graph.structure.ensure_csr()
+        w_aug, table, bias = self._operands(D)
+        token = torch.zeros(self.src_feat, dtype=torch.float32, device=w_aug.device)
+        tab = _lib.coded_table(w_aug, token, 1.0)
+        code = _lib.node_code(node_types, self.src_feat, None, None)
+        ci = _lib.CodedInput(code, tab, token, self.src_feat, 1.0)
+        out, _, _ = _lib.gat_fwd_coded(struct, H, D, ci, table.contiguous(), graph.edge_types_csc(),
+                                       self.leaky_relu.negative_slope, bias, self.activation.weight, False)
+        return out
+
     def forward(self, graph: Graph, feat, get_attention=False):
         if isinstance(feat, tuple):
             raise NotImplementedError("bipartite (src, dst) inputs are not used by MAGIC and have no HIP kernel")
@@ -369,11 +394,16 @@ class GAT(nn.Module):
                                      concat_out=self.concat_out))
         self.head = nn.Identity()
 
-    def forward(self, g, input_feature, return_hidden=False):
+    def forward(self, g, input_feature, return_hidden=False, node_types=None):
+        """``node_types``: the caller's word that ``input_feature`` is ``one_hot(node_types)``; the first layer then
+        reads the types instead of the matrix where it can (inference)."""
         h = input_feature
         hidden_list = []
         for layer in range(self.n_layers):
-            h = self.gats[layer](g, h)
+            if layer == 0 and node_types is not None and self.n_layers > 1 and self.gats[0].onehot_input_ok(g):
+                h = self.gats[0].forward_onehot(g, node_types)
+            else:
+                h = self.gats[layer](g, h)
             hidden_list.append(h)
         if return_hidden:
             return self.head(h), hidden_list

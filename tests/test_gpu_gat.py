@@ -303,6 +303,23 @@ def test_embed_matches_oracle_and_is_deterministic(cuda):
     assert rel_err(e1, eo) < 1e-4
     assert row_rel_err(e1, eo) < 1e-4   # per node, relative to that node's own embedding
     assert torch.equal(e1, e2)   # no atomics anywhere: bitwise reproducible
+    # one-hot node types in: the first layer ran on the type ids (no one-hot matrix, no projection launch); the
+    # dense projection of the materialised matrix gives the same embeddings to rounding
+    from magic_amd import _lib
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    with torch.no_grad():
+        mine.embed(g)
+        coded_names = set(_lib.prof_read(160))
+        _lib.prof_reset()
+        mine.coded_input = False
+        e3 = mine.embed(g)
+        dense_names = set(_lib.prof_read(160))
+    _lib.prof_enable(False)
+    _lib.prof_reset()
+    mine.coded_input = True
+    assert "node_code" in coded_names and "node_code" not in dense_names
+    assert rel_err(e1, e3) < 1e-5 and row_rel_err(e1, e3) < 1e-4
 
 
 def test_batch_level_train_loop(cuda):
