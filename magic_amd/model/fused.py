@@ -88,11 +88,11 @@ class FusedGMAEFn(torch.autograd.Function):
             if l == 0 and coded:
                 # every value the projected input row can take, and the row each node maps to
                 scale0 = cfg.scale if mask is not None else 1.0
-                tab = _lib.coded_table(w_aug, token, scale0)
-                code = _lib.node_code(cfg.node_types, cfg.n_dim, mask, cfg.token_rows)
-                ci = _lib.CodedInput(code, tab, token, cfg.n_dim, scale0)
-                _, pre, stat = _lib.gat_fwd_coded(s, H, D, ci, table.contiguous(), cfg.etype, cfg.slope, bias, prelu_w,
-                                                  True, out=out_l)
+                tok = token.detach().reshape(-1)
+                tab = torch.ops.magic.coded_table(w_aug, tok, scale0)
+                code = torch.ops.magic.node_code(cfg.node_types, cfg.n_dim, mask, cfg.token_rows)
+                _, pre, stat = ops.gat_fwd_coded(s, H, D, ops.Coded(code, tab, tok, scale0), table.contiguous(),
+                                                 cfg.etype, cfg.slope, bias, prelu_w, True, out=out_l)
                 saved += [code, tab, stat, pre]
                 inp = out_l
                 continue
@@ -174,11 +174,11 @@ class FusedGMAEFn(torch.autograd.Function):
             inp = x_in if l == 0 else enc[:, (l - 1) * C:l * C]
             if l == 0 and ctx.coded:
                 # hs / score hold the code words and the table here
-                ci = _lib.CodedInput(hs, score, ctx.token, cfg.n_dim, cfg.scale if mask is not None else 1.0)
+                cd = ops.Coded(hs, score, ctx.token, cfg.scale if mask is not None else 1.0)
                 d_y = d_y_next      # (its residual columns hold d_pre, finished by layer 1's input-gradient epilogue)
-                d_table = _lib.gat_bwd_coded(s, H, D, ci, stat, table, cfg.etype_csr, cfg.e_dim, cfg.slope, None,
-                                             None, None, d_pre, d_pre, d_y, False)[0]
-                grads[0], d_token = _lib.coded_weight_grad(ci, d_y, w_aug)
+                d_table = ops.gat_bwd_coded(s, H, D, cd, stat, table, cfg.etype_csr, cfg.e_dim, cfg.slope, None,
+                                            None, None, d_pre, d_pre, d_y, False)[0]
+                grads[0], d_token = ops.coded_weight_grad(cd, d_y, w_aug)
                 grads[1] = d_table
                 grads[2] = bias_grad
                 grads[3] = prelu_grad.view_as(prelu_w)

@@ -307,11 +307,11 @@ class GATConv(nn.Module):
         struct = graph.structure.ensure_csr()
         w_aug, table, bias = self._operands(D)
         token = torch.zeros(self.src_feat, dtype=torch.float32, device=w_aug.device)
-        tab = _lib.coded_table(w_aug, token, 1.0)
-        code = _lib.node_code(node_types, self.src_feat, None, None)
-        ci = _lib.CodedInput(code, tab, token, self.src_feat, 1.0)
-        out, _, _ = _lib.gat_fwd_coded(struct, H, D, ci, table.contiguous(), graph.edge_types_csc(),
-                                       self.leaky_relu.negative_slope, bias, self.activation.weight, False)
+        tab = torch.ops.magic.coded_table(w_aug, token, 1.0)
+        code = torch.ops.magic.node_code(node_types, self.src_feat, None, None)
+        out, _, _ = ops.gat_fwd_coded(struct, H, D, ops.Coded(code, tab, token, 1.0), table.contiguous(),
+                                      graph.edge_types_csc(), self.leaky_relu.negative_slope, bias,
+                                      self.activation.weight, False)
         return out
 
     def forward(self, graph: Graph, feat, get_attention=False):

@@ -218,6 +218,125 @@ def gat_bwd(struct, H, D, hs, eh, stat, ee_table, etype_csr, ee_csc, e_dim, slop
     return _none(d_table), _none(d_logit), _none(d_bias), _none(d_prelu)
 
 
+# ---- coded first-layer input (csrc/coded.hip): table of the values a one-hot / mask-token row can take, the row
+# index per node, the sweeps that fetch rows by it and the grouped-sum weight gradient ------------------------
+def _coded(code, table, token, scale):
+    return _lib.CodedInput(code, table, token, token.numel(), scale)
+
+
+def _coded_table(w_aug, token, scale: float):
+    return _lib.coded_table(w_aug, token, scale)
+
+
+def _coded_table_fake(w_aug, token, scale):
+    n_dim = w_aug.shape[1]
+    return w_aug.new_empty((n_dim + 1 + (1 << n_dim), w_aug.shape[0]))
+
+
+_register("coded_table", "(Tensor w_aug, Tensor token, float scale) -> Tensor", _coded_table, _coded_table_fake)
+
+
+def _node_code(node_type, n_dim: int, keep_mask, mask_rows):
+    return _lib.node_code(node_type, n_dim, keep_mask, mask_rows)
+
+
+def _node_code_fake(node_type, n_dim, keep_mask, mask_rows):
+    return node_type.new_empty((node_type.numel(),), dtype=torch.int32)
+
+
+_register("node_code", "(Tensor node_type, int n_dim, Tensor? keep_mask, Tensor? mask_rows) -> Tensor", _node_code,
+          _node_code_fake)
+
+
+def _gat_fwd_coded_(p0, p1, p2, p3, p4, p5, p6, p7, in_src, n_heads: int, head_dim: int, code, table, token,
+                    scale: float, ee_table, etype_csc, slope: float, bias, prelu_w, want_pre: bool, out):
+    s = _struct_in(out.shape[0], (p0, p1, p2, p3, p4, p5, p6, p7), in_src, None)
+    _, pre, stat = _lib.gat_fwd_coded(s, n_heads, head_dim, _coded(code, table, token, scale), ee_table, etype_csc,
+                                      slope, bias, prelu_w, want_pre, out=out)
+    return pre if pre is not None else _empty(table), stat
+
+
+def _gat_fwd_coded__fake(p0, p1, p2, p3, p4, p5, p6, p7, in_src, n_heads, head_dim, code, table, token, scale,
+                         ee_table, etype_csc, slope, bias, prelu_w, want_pre, out):
+    n, c = out.shape[0], n_heads * head_dim
+    return table.new_empty((n, c) if want_pre else (0,)), table.new_empty((n, n_heads, 2))
+
+
+_register("gat_fwd_coded_", "(" + _PLAN.format("in_") + ", Tensor in_src, int n_heads, int head_dim, Tensor code, "
+          "Tensor table, Tensor token, float scale, Tensor ee_table, Tensor etype_csc, float slope, Tensor? bias, "
+          "Tensor? prelu_w, bool want_pre, Tensor(a!) out) -> (Tensor, Tensor)", _gat_fwd_coded_, _gat_fwd_coded__fake)
+
+
+def _gat_bwd_coded_(i0, i1, i2, i3, i4, i5, i6, i7, o0, o1, o2, o3, o4, o5, o6, o7, in_pos, out_dst, out_pos,
+                    n_heads: int, head_dim: int, code, table, token, scale: float, stat, ee_table, etype_csr, e_dim: int,
+                    slope: float, pre, act_out, prelu_w, d_out, d_pre, d_y, want_bias: bool):
+    s = SimpleNamespace(num_nodes=code.shape[0], num_edges=int(out_dst.numel()),
+                        plan_in=_plan(i0, i1, i2, i3, i4, i5, i6, i7), plan_out=_plan(o0, o1, o2, o3, o4, o5, o6, o7),
+                        in_pos=in_pos, out_dst=out_dst, out_pos=out_pos)
+    d_table, d_bias, d_prelu = _lib.gat_bwd_coded(s, n_heads, head_dim, _coded(code, table, token, scale), stat, ee_table,
+                                                  etype_csr, e_dim, slope, pre, act_out, prelu_w, d_out, d_pre, d_y,
+                                                  want_bias)
+    e = _empty(table)
+    return d_table, d_bias if d_bias is not None else e, d_prelu if d_prelu is not None else e
+
+
+def _gat_bwd_coded__fake(i0, i1, i2, i3, i4, i5, i6, i7, o0, o1, o2, o3, o4, o5, o6, o7, in_pos, out_dst, out_pos,
+                         n_heads, head_dim, code, table, token, scale, stat, ee_table, etype_csr, e_dim, slope, pre,
+                         act_out, prelu_w, d_out, d_pre, d_y, want_bias):
+    return (table.new_empty((e_dim, n_heads)), table.new_empty(n_heads * head_dim if want_bias else 0),
+            table.new_empty(1 if prelu_w is not None else 0))
+
+
+_register("gat_bwd_coded_", "(" + _PLAN.format("in_") + ", " + _PLAN.format("out_") + ", Tensor in_pos, Tensor out_dst, "
+          "Tensor out_pos, int n_heads, int head_dim, Tensor code, Tensor table, Tensor token, float scale, Tensor stat, "
+          "Tensor ee_table, Tensor etype_csr, int e_dim, float slope, Tensor? pre, Tensor? act_out, Tensor? prelu_w, "
+          "Tensor(a!) d_out, Tensor(b!) d_pre, Tensor(c!) d_y, bool want_bias) -> (Tensor, Tensor, Tensor)",
+          _gat_bwd_coded_, _gat_bwd_coded__fake)
+
+
+def _coded_weight_grad(code, table, token, scale: float, d_y, w_aug):
+    return _lib.coded_weight_grad(_coded(code, table, token, scale), d_y, w_aug)
+
+
+def _coded_weight_grad_fake(code, table, token, scale, d_y, w_aug):
+    return w_aug.new_empty(w_aug.shape), w_aug.new_empty((1, w_aug.shape[1]))
+
+
+_register("coded_weight_grad", "(Tensor code, Tensor table, Tensor token, float scale, Tensor d_y, Tensor w_aug) "
+          "-> (Tensor, Tensor)", _coded_weight_grad, _coded_weight_grad_fake)
+
+
+class Coded:
+    """Operands of a coded-input layer as the operators take them (code words, table, token, dropout scale)."""
+
+    def __init__(self, code, table, token, scale):
+        self.code, self.table, self.scale = code, table, float(scale)
+        self.token = token.detach().reshape(-1).contiguous()
+
+
+def gat_fwd_coded(struct, H, D, cd: Coded, ee_table, etype_csc, slope, bias, prelu_w, want_pre, out=None):
+    """(out, pre | None, stat) of ``torch.ops.magic.gat_fwd_coded_``."""
+    if out is None:
+        out = torch.empty(struct.num_nodes, H * D, dtype=torch.float32, device=cd.code.device)
+    pre, stat = torch.ops.magic.gat_fwd_coded_(*plan_tensors(struct.plan_in), struct.in_src, H, D, cd.code, cd.table,
+                                               cd.token, cd.scale, ee_table, etype_csc, float(slope), bias, prelu_w,
+                                               bool(want_pre), out)
+    return out, _none(pre), stat
+
+
+def gat_bwd_coded(struct, H, D, cd: Coded, stat, ee_table, etype_csr, e_dim, slope, pre, act_out, prelu_w, d_out, d_pre,
+                  d_y, want_bias):
+    d_table, d_bias, d_prelu = torch.ops.magic.gat_bwd_coded_(
+        *plan_tensors(struct.plan_in), *plan_tensors(struct.plan_out), struct.in_pos, struct.out_dst, struct.out_pos,
+        H, D, cd.code, cd.table, cd.token, cd.scale, stat, ee_table, etype_csr, int(e_dim), float(slope), pre, act_out,
+        prelu_w, d_out, d_pre, d_y, bool(want_bias))
+    return d_table, _none(d_bias), _none(d_prelu)
+
+
+def coded_weight_grad(cd: Coded, d_y, w_aug):
+    return torch.ops.magic.coded_weight_grad(cd.code, cd.table, cd.token, cd.scale, d_y, w_aug)
+
+
 def proj_fwd(x, w, out_c, n_score, res_c, x_mask=None, x_scale=1.0):
     hs, score, res = torch.ops.magic.proj_fwd(x, w, out_c, n_score, res_c, x_mask, float(x_scale))
     return hs, _none(score), _none(res)

@@ -72,6 +72,35 @@ int main() {
                          0.2f, nullptr, nullptr, 0, nullptr, 1.f, nullptr, nullptr, 64, nullptr, nullptr, nullptr, nullptr,
                          0, nullptr),
            MAGIC_ERR_INVALID_ARG);
+    // coded first-layer input
+    if (magic_coded_table_rows(5) != 5 + 1 + 32 || magic_coded_table_rows(MAGIC_CODED_MAX_DIM + 1) != 0) ++failures;
+    EXPECT(magic_coded_table(0, 136, dummy, 5, dummy, 1.f, dummy, 136, nullptr), MAGIC_ERR_INVALID_ARG);
+    EXPECT(magic_coded_table(5, 136, dummy, 4, dummy, 1.f, dummy, 136, nullptr), MAGIC_ERR_INVALID_ARG);  // ld_w < n_dim
+    EXPECT(magic_node_code(10, MAGIC_CODED_MAX_DIM + 1, (const int64_t *)dummy, nullptr, 0, nullptr, (uint32_t *)dummy, nullptr),
+           MAGIC_ERR_INVALID_ARG);
+    EXPECT(magic_node_code(0, 5, nullptr, nullptr, 0, nullptr, nullptr, nullptr), MAGIC_OK);
+    magic_coded_input ci;
+    std::memset(&ci, 0, sizeof ci);
+    EXPECT(magic_gat_fwd_coded(4, 4, 4, 16, &plan, nullptr, nullptr, dummy, nullptr, 0.2f, nullptr, nullptr, dummy, 64, nullptr,
+                               nullptr, nullptr, 0, nullptr),
+           MAGIC_ERR_INVALID_ARG);
+    ci.code = (const uint32_t *)dummy, ci.table = dummy, ci.token = dummy, ci.n_dim = 5, ci.ld_table = 100;  // narrower than 2C+2H
+    plan.ptr = (const int32_t *)dummy;
+    EXPECT(magic_gat_fwd_coded(4, 4, 4, 16, &plan, nullptr, &ci, dummy, nullptr, 0.2f, nullptr, nullptr, dummy, 64, nullptr,
+                               nullptr, nullptr, 0, nullptr),
+           MAGIC_ERR_INVALID_ARG);
+    ci.ld_table = 136;
+    EXPECT(magic_gat_fwd_coded(4, 4, 1, 8, &plan, nullptr, &ci, dummy, nullptr, 0.2f, nullptr, nullptr, dummy, 8, nullptr, nullptr,
+                               nullptr, 0, nullptr),
+           MAGIC_ERR_UNSUPPORTED);  // compiled for four heads
+    (void)magic_coded_weight_grad_workspace_bytes(136, 5);
+    EXPECT(magic_coded_weight_grad(10, 136, nullptr, dummy, 136, dummy, 5, dummy, 5, nullptr, nullptr, 0, nullptr),
+           MAGIC_ERR_INVALID_ARG);
+    EXPECT(magic_coded_weight_grad(10, 136, &ci, dummy, 100, dummy, 5, dummy, 5, nullptr, nullptr, 0, nullptr),
+           MAGIC_ERR_INVALID_ARG);  // ld_dy < m
+    EXPECT(magic_coded_weight_grad(10, 136, &ci, dummy, 136, dummy, 5, dummy, 5, nullptr, nullptr, 0, nullptr),
+           MAGIC_ERR_WORKSPACE);
+    plan.ptr = nullptr;
     // loss, read-out, sampling helpers, scatter
     (void)magic_sce_workspace_bytes(100, 8);
     EXPECT(magic_sce_fwd_bwd(-1, 8, 0, nullptr, nullptr, 8, nullptr, 8, 3.f, 1.f, nullptr, nullptr, nullptr, nullptr, 0, nullptr),

@@ -13,8 +13,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarise  # noqa: E402
 
-WANT = ("k_knn_filter_bf16", "k_knn_mfma", "k_proj_gemm", "k_proj_dw_wide", "k_proj_rows", "k_proj_dw<", "k_proj<",
-        "k_proj_stream")
+WANT = ("k_knn_filter_bf16", "k_knn_mfma", "k_proj_gemm", "k_proj_dw_wide", "k_proj_rows", "k_proj_strip", "k_proj_dw<",
+        "k_proj<", "k_proj_stream")
 CUS = 256
 
 
@@ -24,6 +24,7 @@ def main():
     print(f"{'kernel':46s} {'dispatches':>10s} {'MFMA_BUSY':>14s} {'BUSY_CU':>14s} {'GUI_ACTIVE':>12s} "
           f"{'busy share':>11s} {'MfmaUtil':>9s}")
     for d in sys.argv[1:]:
+        print(f"# {os.path.basename(os.path.normpath(d))}")
         acc = summarise(os.path.join(d, "**", "*counter_collection.csv"))
         for k in sorted(acc):
             if not k.startswith(WANT) or "reduce" in k or "sums" in k:

@@ -35,4 +35,6 @@ bash tools/pmc_pass.sh mfma_th "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_
 bash tools/pmc_knn.sh mfma_knn "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVES"
 python3 tools/pmc_mfma.py gpurun_out/pmc_mfma_ss gpurun_out/pmc_mfma_th gpurun_out/pmc_mfma_knn > profiles/${tag}_pmc_mfma.txt
 cp profiles/traffic.json profiles/${tag}_pmc_summary_*.txt profiles/${tag}_pmc_mfma.txt gpurun_out/
+# the raw traces and counter dumps stay on the box (only 64 MiB travel back)
+rm -rf $out/stats_$tag $out/tr_${tag}_* $out/pmc_rd_* $out/pmc_wr_* $out/pmc_mfma_*
 echo profile set $tag done
