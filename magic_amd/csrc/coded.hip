@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_coded_dw_partial(DwArgs a) {
             if (cw > nd) {
                 const uint32_t b = cw - nd - 1u;
 #pragma unroll
-                for (int j = 0; j < ND; ++j) S[j] = fmaf(d[r], (float)((b >> j) & 1u), S[j]);
+                for (int j = 0; j < ND; ++j) S[j] = fmaf(d[r], ((b >> j) & 1u) ? 1.f : 0.f, S[j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < ND; ++j) A[j] = fmaf(d[r], cw == (uint32_t)j ? 1.f : 0.f, A[j]);
