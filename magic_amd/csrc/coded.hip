@@ -14,13 +14,14 @@
 //   S_j[m] = scale * sum over masked u with keep_j(u) of d_y[u, m]
 //   dW[m, j] = A_j[m] + token[j] * S_j[m],     d_token[j] = sum_m W[m, j] * S_j[m]
 // -- one pass over d_y with the code words, no [N, n_dim] input matrix and no input gradient.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
 
 constexpr int ND_MAX = MAGIC_CODED_MAX_DIM;  // 13: the table has n_dim + 1 + 2^n_dim rows
 constexpr int DW_ROWS = 16;                  // rows a block takes per trip (their loads are in flight together)
-constexpr int DW_GRID = 2048;                // partial tables
+constexpr int DW_GRID = 2048;                // partial tables at most (a multiple of DW_FOLD)
 constexpr int DW_FOLD = 32;                  // second-stage partial tables
 
 // thread = (table row, 4 columns)
@@ -83,7 +84,8 @@ struct DwArgs {
     const float *dy;
     int64_t ld_dy;
     float scale;
-    float *part;   // [DW_GRID][2][n_dim][M]
+    int grid;      // partial tables of this launch (a multiple of DW_FOLD)
+    float *part;   // [grid][2][n_dim][M]
     float *part2;  // [DW_FOLD][2][n_dim][M]
     const float *w;  // [M, ld_w] the layer's augmented weight
     int64_t ld_w;
@@ -93,9 +95,72 @@ struct DwArgs {
     float *d_token;  // [n_dim]
 };
 
-// thread = column m (blockIdx.y selects the window of blockDim.x columns); the block walks its rows in a fixed order.  The
-// code word is the same for every thread of the block: one scalar branch per row picks the accumulator set, the
-// adds themselves are multiplications by 0 / 1 held in scalar registers (no per-column branches).
+// Rows of float4 (M and the row pitch multiples of 4, 16-byte aligned base): thread = (row slot, column quad) of the
+// block's column window of `wq` quads, R = 256 / wq row slots.  A trip takes QK * R consecutive rows, QK float4 loads
+// per thread in flight; a row's code word picks the accumulators through 0 / 1 factors (rows differ between the lanes
+// of a wave: no branches).  Each slot adds its rows in ascending order, the slots are added in slot order.
+constexpr int QK = 8;
+template <int ND>
+__global__ __launch_bounds__(256) void k_coded_dw_quads(DwArgs a, int wq, int R) {
+    __shared__ float4 red[256];
+    const int q = threadIdx.x % wq, rs = threadIdx.x / wq;
+    const int c4 = (blockIdx.y * wq + q) * 4;
+    const bool live = rs < R && c4 < a.M;
+    const int cc = c4 < a.M ? c4 : 0;
+    float4 A[ND], S[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) A[j] = S[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t per_trip = (int64_t)QK * R;
+    const int64_t n_trips = (a.n + per_trip - 1) / per_trip;
+    const uint32_t nd = (uint32_t)a.n_dim;
+    const int rsc = rs < R ? rs : 0;
+    for (int64_t trip = blockIdx.x; trip < n_trips; trip += gridDim.x) {
+        float4 d[QK];
+        uint32_t c[QK];
+#pragma unroll
+        for (int k = 0; k < QK; ++k) {
+            const int64_t u = trip * per_trip + (int64_t)k * R + rsc;
+            const int64_t uc = u < a.n ? u : a.n - 1;
+            d[k] = *reinterpret_cast<const float4 *>(a.dy + uc * a.ld_dy + cc);
+            c[k] = u < a.n ? a.code[uc] : nd;  // (past the end: the dropped row, which contributes nothing)
+        }
+#pragma unroll
+        for (int k = 0; k < QK; ++k) {
+            const bool masked = c[k] > nd;
+            const uint32_t b = masked ? c[k] - nd - 1u : 0u;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const float fa = c[k] == (uint32_t)j ? 1.f : 0.f;
+                const float fs = ((b >> j) & 1u) ? 1.f : 0.f;
+                A[j].x = fmaf(d[k].x, fa, A[j].x), A[j].y = fmaf(d[k].y, fa, A[j].y);
+                A[j].z = fmaf(d[k].z, fa, A[j].z), A[j].w = fmaf(d[k].w, fa, A[j].w);
+                S[j].x = fmaf(d[k].x, fs, S[j].x), S[j].y = fmaf(d[k].y, fs, S[j].y);
+                S[j].z = fmaf(d[k].z, fs, S[j].z), S[j].w = fmaf(d[k].w, fs, S[j].w);
+            }
+        }
+    }
+    float *p = a.part + (size_t)blockIdx.x * 2 * a.n_dim * a.M;
+#pragma unroll
+    for (int j = 0; j < 2 * ND; ++j) {
+        if (j % ND >= a.n_dim) continue;
+        float4 t = j < ND ? A[j % ND] : S[j % ND];
+        __syncthreads();
+        red[threadIdx.x] = t;
+        __syncthreads();
+        if (rs == 0 && live) {
+            for (int k = 1; k < R; ++k) {
+                const float4 o = red[k * wq + q];
+                t.x += o.x, t.y += o.y, t.z += o.z, t.w += o.w;
+            }
+            t.x *= a.scale, t.y *= a.scale, t.z *= a.scale, t.w *= a.scale;
+            *reinterpret_cast<float4 *>(p + ((size_t)(j < ND ? 0 : a.n_dim) + j % ND) * a.M + c4) = t;
+        }
+    }
+}
+
+// Any M / pitch: thread = column m (blockIdx.y selects the window of blockDim.x columns); the block walks its rows in a
+// fixed order.  The code word is the same for every thread of the block: one scalar branch per row picks the
+// accumulator set, the adds themselves are multiplications by 0 / 1 held in scalar registers (no per-column branches).
 template <int ND>
 __global__ __launch_bounds__(256) void k_coded_dw_partial(DwArgs a) {
     const int m = blockIdx.y * blockDim.x + threadIdx.x;
@@ -140,12 +205,12 @@ __global__ __launch_bounds__(256) void k_coded_dw_partial(DwArgs a) {
     }
 }
 
-// DW_GRID partial tables -> DW_FOLD (block y adds its run of tables in order)
+// partial tables -> DW_FOLD (block y adds its run of tables in order)
 __global__ __launch_bounds__(256) void k_coded_dw_fold(DwArgs a) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     const int n_out = 2 * a.n_dim * a.M;
     if (o >= n_out) return;
-    constexpr int per = DW_GRID / DW_FOLD;
+    const int per = a.grid / DW_FOLD;
     float t = 0.f;
     for (int k = 0; k < per; ++k) t += a.part[(size_t)(blockIdx.y * per + k) * n_out + o];
     a.part2[(size_t)blockIdx.y * n_out + o] = t;
@@ -174,6 +239,13 @@ __global__ __launch_bounds__(256) void k_coded_dw_final(DwArgs a) {
         __syncthreads();
     }
     if (threadIdx.x == 0 && a.d_token) a.d_token[j] = red[0];
+}
+
+// a block should take several trips: its partial table costs as much traffic as a few rows of d_y
+int partial_tables(int64_t n_rows, int64_t rows_per_trip) {
+    const int64_t trips = (n_rows + rows_per_trip - 1) / rows_per_trip;
+    int64_t g = trips / 4 / DW_FOLD * DW_FOLD;
+    return (int)(g < DW_FOLD ? DW_FOLD : (g > DW_GRID ? DW_GRID : g));
 }
 
 }  // namespace
@@ -237,13 +309,28 @@ int magic_coded_weight_grad(int64_t n_nodes, int32_t m, const magic_coded_input 
     // threads, 520 -> three of 192
     const int n_win = (m + 255) / 256;
     const int width = ((m + n_win - 1) / n_win + 63) / 64 * 64;
-    dim3 grid(DW_GRID, n_win);
-    if (a.n_dim <= 5)
-        MAGIC_LAUNCH("coded_dw_partial", k_coded_dw_partial<5>, grid, width, 0, stream, a);
-    else if (a.n_dim <= 8)
-        MAGIC_LAUNCH("coded_dw_partial", k_coded_dw_partial<8>, grid, width, 0, stream, a);
-    else
-        MAGIC_LAUNCH("coded_dw_partial", k_coded_dw_partial<ND_MAX>, grid, width, 0, stream, a);
+    const bool quads = (m & 3) == 0 && (ld_dy & 3) == 0 && ((uintptr_t)dy & 15) == 0 && !getenv("MAGIC_CODED_DW_COLS");
+    if (quads) {
+        // column windows of at most 64 quads, equal width: 136 columns -> 34 quads x 7 row slots, 520 -> 3 x (44 x 5)
+        const int m4 = m / 4, qwin = (m4 + 63) / 64, wq = (m4 + qwin - 1) / qwin, R = 256 / wq;
+        a.grid = partial_tables(n_nodes, (int64_t)QK * R);
+        dim3 qgrid(a.grid, qwin);
+        if (a.n_dim <= 5)
+            MAGIC_LAUNCH("coded_dw_partial", k_coded_dw_quads<5>, qgrid, 256, 0, stream, a, wq, R);
+        else if (a.n_dim <= 8)
+            MAGIC_LAUNCH("coded_dw_partial", k_coded_dw_quads<8>, qgrid, 256, 0, stream, a, wq, R);
+        else
+            MAGIC_LAUNCH("coded_dw_partial", k_coded_dw_quads<ND_MAX>, qgrid, 256, 0, stream, a, wq, R);
+    } else {
+        a.grid = partial_tables(n_nodes, DW_ROWS);
+        dim3 grid(a.grid, n_win);
+        if (a.n_dim <= 5)
+            MAGIC_LAUNCH("coded_dw_partial", k_coded_dw_partial<5>, grid, width, 0, stream, a);
+        else if (a.n_dim <= 8)
+            MAGIC_LAUNCH("coded_dw_partial", k_coded_dw_partial<8>, grid, width, 0, stream, a);
+        else
+            MAGIC_LAUNCH("coded_dw_partial", k_coded_dw_partial<ND_MAX>, grid, width, 0, stream, a);
+    }
     dim3 fgrid((unsigned)((tab + 255) / 256), DW_FOLD);
     MAGIC_LAUNCH("coded_dw_fold", k_coded_dw_fold, fgrid, 256, 0, stream, a);
     MAGIC_LAUNCH("coded_dw_final", k_coded_dw_final, a.n_dim, 256, 0, stream, a);
