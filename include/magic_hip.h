@@ -192,6 +192,20 @@ int magic_gat_fwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t hea
                   const float *prelu_w,
                   float *out, int64_t ld_out, float *pre, float *attn, float *stat,
                   void *workspace, size_t workspace_bytes, void *stream);
+/* magic_gat_fwd for a layer of which only some output rows are read -- the decoder: the loss takes
+ * recon[mask_nodes] alone (model/autoencoder.py:240-245).  dst_active [N] uint8 marks those rows
+ * (NULL = all: magic_gat_fwd).  An unmarked destination is treated as a node without in-edges: none
+ * of its edges is visited, out = bias (+ res), stat = (.., +inf), so that every attention weight
+ * magic_gat_bwd[_active] recomputes from it is an exact zero.  The marked rows are bit for bit those
+ * of magic_gat_fwd.  attn must be NULL. */
+int magic_gat_fwd_active(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t head_dim,
+                         const magic_plan *in_plan, const int32_t *in_src, const int32_t *in_dst,
+                         const float *hs, int64_t ld_hs, const float *eh, const float *et, int64_t ld_score,
+                         const float *ee_table, const int32_t *etype_csc, const float *ee_csc,
+                         float negative_slope, const float *bias, const float *res, int64_t ld_res,
+                         const uint8_t *res_mask, float res_scale, const float *prelu_w,
+                         float *out, int64_t ld_out, float *pre, float *attn, float *stat,
+                         const uint8_t *dst_active, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Coded input of the first encoder layer.  The reference feeds that layer one_hot(node type)
@@ -351,6 +365,22 @@ int magic_gat_bwd(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t hea
                   float *d_logit,
                   float *d_bias, float *d_prelu_w,
                   void *workspace, size_t workspace_bytes, void *stream);
+/* magic_gat_bwd when gradient arrives at the marked destinations only (dst_active [N] uint8; the rows
+ * of d_out at unmarked destinations must be zero, as the loss gradient of model/autoencoder.py:242-245
+ * is outside mask_nodes).  The edges into unmarked destinations contribute exact zeros; the sweeps
+ * gather nothing for them (their destination ids are rewritten in the workspace to one unmarked node,
+ * whose rows stay in cache) and the destination pass skips unmarked nodes.  Same results as
+ * magic_gat_bwd on such a d_out (up to the sign of zeros).  No d_logit output. */
+int magic_gat_bwd_active(int32_t n_nodes, int32_t n_edges, int32_t n_heads, int32_t head_dim,
+                         const magic_plan *in_plan, const int32_t *in_pos,
+                         const magic_plan *out_plan, const int32_t *out_dst, const int32_t *out_pos,
+                         const float *hs, int64_t ld_hs, const float *eh, int64_t ld_score, const float *stat,
+                         const float *ee_table, const int32_t *etype_csr, const float *ee_csc, int32_t e_dim,
+                         float negative_slope, const float *pre, const float *act_out, int64_t ld_act,
+                         const float *prelu_w, const float *d_out, int64_t ld_dout,
+                         float *d_pre, int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table,
+                         float *d_bias, float *d_prelu_w, const uint8_t *dst_active,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Masked-node feature reconstruction loss, forward and backward in one pass

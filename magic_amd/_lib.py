@@ -74,10 +74,16 @@ SYMBOLS = {
     "magic_gat_fwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, c_vp,
                               c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp,
                               c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "magic_gat_fwd_active": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, c_vp,
+                                     c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_f32,
+                                     c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_gat_bwd_workspace_bytes": (c_sz, [c_i32] * 7),
     "magic_gat_bwd": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, C.POINTER(MagicPlan), c_vp,
                               c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_i64,
                               c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "magic_gat_bwd_active": (c_i32, [c_i32, c_i32, c_i32, c_i32, C.POINTER(MagicPlan), c_vp, C.POINTER(MagicPlan), c_vp,
+                                     c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_i64,
+                                     c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_coded_table_rows": (c_i64, [c_i32]),
     "magic_coded_table": (c_i32, [c_i32, c_i32, c_vp, c_i64, c_vp, c_f32, c_vp, c_i64, c_vp]),
     "magic_node_code": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -587,10 +593,12 @@ def fold_bwd_multi(layers, grads):
 # ------------------------------------------------------------------------------------- GAT
 def gat_fwd(struct, H: int, D: int, hs, eh, et, ee_table, etype_csc, ee_csc, slope: float, bias, res,
             prelu_w, want_pre: bool, res_mask: Optional[torch.Tensor] = None, res_scale: float = 1.0,
-            out: Optional[torch.Tensor] = None, want_attn: bool = True, want_stat: bool = False):
+            out: Optional[torch.Tensor] = None, want_attn: bool = True, want_stat: bool = False,
+            dst_active: Optional[torch.Tensor] = None):
     """``out`` may be a preallocated [N,C] view (unit inner stride, 16-byte aligned rows), e.g. a column
     block of the concatenated hidden-state buffer.  ``pre`` is only written by the kernel when the
-    PReLU slope is <= 0 (otherwise backward recovers it from ``out``).  Returns
+    PReLU slope is <= 0 (otherwise backward recovers it from ``out``).  ``dst_active`` [N] uint8 marks the
+    destinations whose output row is read (``magic_gat_fwd_active``; the others get bias + residual).  Returns
     (out, pre | None, attn [E,H] | None, stat [N,H,2] | None); ``stat`` is what ``gat_bwd`` needs."""
     lib = load()
     from .graph import LIGHT_MAX
@@ -610,19 +618,32 @@ def gat_fwd(struct, H: int, D: int, hs, eh, et, ee_table, etype_csc, ee_csc, slo
     assert eh.stride(0) == et.stride(0)
     if res_mask is not None:
         assert res_mask.dtype == torch.uint8 and res_mask.shape == (N, Cc) and res_mask.is_contiguous()
-    _check(lib.magic_gat_fwd(N, E, H, D, C.byref(plan), _dev(struct.in_src), _dev(struct.in_dst),
-                             _dev(hs, torch.float32, "hs"), hs.stride(0), _dev(eh, torch.float32, "eh"),
-                             _dev(et, torch.float32, "et"), eh.stride(0), _dev(ee_table), _dev(etype_csc), _dev(ee_csc),
-                             float(slope), _dev(bias), _dev(res), res.stride(0) if res is not None else 0,
-                             _dev(res_mask), float(res_scale), _dev(prelu_w), _dev(out), out.stride(0), _dev(pre),
-                             _dev(attn), _dev(stat), ws.data_ptr(), ws.numel(), _stream()), "magic_gat_fwd")
+    head = (N, E, H, D, C.byref(plan), _dev(struct.in_src), _dev(struct.in_dst),
+            _dev(hs, torch.float32, "hs"), hs.stride(0), _dev(eh, torch.float32, "eh"),
+            _dev(et, torch.float32, "et"), eh.stride(0), _dev(ee_table), _dev(etype_csc), _dev(ee_csc),
+            float(slope), _dev(bias), _dev(res), res.stride(0) if res is not None else 0,
+            _dev(res_mask), float(res_scale), _dev(prelu_w), _dev(out), out.stride(0), _dev(pre),
+            _dev(attn), _dev(stat))
+    if dst_active is not None:
+        _check_active(dst_active, N)
+        _check(lib.magic_gat_fwd_active(*head, _dev(dst_active), ws.data_ptr(), ws.numel(), _stream()),
+               "magic_gat_fwd_active")
+    else:
+        _check(lib.magic_gat_fwd(*head, ws.data_ptr(), ws.numel(), _stream()), "magic_gat_fwd")
     return out, pre, attn, stat
 
 
+def _check_active(dst_active, n):
+    if dst_active.dtype != torch.uint8 or dst_active.shape != (n,) or not dst_active.is_contiguous():
+        raise MagicHipError("dst_active must be a contiguous uint8 tensor with one entry per node")
+
+
 def gat_bwd(struct, H: int, D: int, hs, eh, stat, ee_table, etype_csr, ee_csc, e_dim: int, slope: float, pre,
-            act_out, prelu_w, d_out, d_pre, d_y, want_bias: bool, want_dlogit: bool = False):
+            act_out, prelu_w, d_out, d_pre, d_y, want_bias: bool, want_dlogit: bool = False,
+            dst_active: Optional[torch.Tensor] = None):
     """Fills d_pre [N,>=C] and d_y [N,>=C+2H] (views allowed, unit inner stride); with
     ``prelu_w is None`` ``d_pre`` may be the very tensor passed as ``d_out`` (no copy is made).
+    ``dst_active`` [N] uint8: the destinations at which ``d_out`` can be non-zero (``magic_gat_bwd_active``).
     ``eh`` [N,H] (row stride allowed), ``stat`` [N,H,2] from ``gat_fwd(want_stat=True)``; the edge term
     as in forward, with the edge types in CSR order.
     Returns (d_ee_table | None, d_logit [E,H] in CSC order | None, d_bias | None, d_prelu_w | None)."""
@@ -643,14 +664,22 @@ def gat_bwd(struct, H: int, D: int, hs, eh, stat, ee_table, etype_csr, ee_csc, e
     d_out = _rows(d_out)
     act_out = _rows(act_out)
     assert stat.shape == (N, H, 2) and stat.is_contiguous() and eh.stride(-1) == 1
-    _check(lib.magic_gat_bwd(N, E, H, D, C.byref(pin), _dev(struct.in_pos), C.byref(pout), _dev(struct.out_dst),
-                             _dev(struct.out_pos), _dev(hs, torch.float32, "hs"), hs.stride(0),
-                             _dev(eh, torch.float32, "eh"), eh.stride(0), _dev(stat, torch.float32, "stat"),
-                             _dev(ee_table), _dev(etype_csr), _dev(ee_csc), int(e_dim), float(slope),
-                             _dev(pre), _dev(act_out), act_out.stride(0) if act_out is not None else 0,
-                             _dev(prelu_w), _dev(d_out, torch.float32, "d_out"), d_out.stride(0),
-                             _dev(d_pre), d_pre.stride(0), _dev(d_y), d_y.stride(0), _dev(d_table), _dev(rec),
-                             _dev(d_bias), _dev(d_prelu), ws.data_ptr(), ws.numel(), _stream()), "magic_gat_bwd")
+    head = (N, E, H, D, C.byref(pin), _dev(struct.in_pos), C.byref(pout), _dev(struct.out_dst),
+            _dev(struct.out_pos), _dev(hs, torch.float32, "hs"), hs.stride(0),
+            _dev(eh, torch.float32, "eh"), eh.stride(0), _dev(stat, torch.float32, "stat"),
+            _dev(ee_table), _dev(etype_csr), _dev(ee_csc), int(e_dim), float(slope),
+            _dev(pre), _dev(act_out), act_out.stride(0) if act_out is not None else 0,
+            _dev(prelu_w), _dev(d_out, torch.float32, "d_out"), d_out.stride(0),
+            _dev(d_pre), d_pre.stride(0), _dev(d_y), d_y.stride(0), _dev(d_table))
+    if dst_active is not None:
+        _check_active(dst_active, N)
+        if want_dlogit:
+            raise MagicHipError("d_logit is not produced together with dst_active")
+        _check(lib.magic_gat_bwd_active(*head, _dev(d_bias), _dev(d_prelu), _dev(dst_active), ws.data_ptr(),
+                                        ws.numel(), _stream()), "magic_gat_bwd_active")
+    else:
+        _check(lib.magic_gat_bwd(*head, _dev(rec), _dev(d_bias), _dev(d_prelu), ws.data_ptr(), ws.numel(),
+                                 _stream()), "magic_gat_bwd")
     return d_table, rec, d_bias, d_prelu
 
 

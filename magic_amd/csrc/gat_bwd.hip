@@ -66,7 +66,45 @@ struct BwdArgs {
     float *ws_table;  // [grid_table, e_dim*H]
     int grid_table;
     CodedIn ci;  // coded layer input (the CODED source sweeps): replaces hs and eh
+    const uint8_t *active;  // [N] 1 = gradient arrives at this destination; null = at all of them
 };
+
+// ---- destinations without incoming gradient ---------------------------------------------------
+// When the caller marks the destinations whose d_out row can be non-zero (the decoder: the masked nodes), the edges
+// into all the others contribute exact zeros: their attention weight is recomputed from the +inf log-sum-exp the
+// forward sweep recorded for them.  The sweeps still stream those edges, but need not gather anything for them from
+// 2 x N different rows: the CSR destination ids are rewritten so that every such edge points at ONE unmarked node
+// (the first among nodes 0..255; without one the ids stay as they are), whose rows then sit in cache, and the
+// destination pass skips the unmarked nodes.
+__global__ __launch_bounds__(256) void k_active_dst(int N, int E, const int32_t *__restrict__ out_dst,
+                                                    const uint8_t *__restrict__ active, int32_t *__restrict__ eff) {
+    __shared__ int first[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool off = (int)threadIdx.x < N && active[threadIdx.x] == 0;
+    const unsigned long long m = __ballot(off);
+    if (lane == 0) first[wave] = m ? wave * 64 + __builtin_ctzll(m) : -1;
+    __syncthreads();
+    int park = -1;
+#pragma unroll
+    for (int w = 3; w >= 0; --w)
+        if (first[w] >= 0) park = first[w];
+    // four edges per thread and trip (both arrays are 16-byte aligned): the four flag lookups are in flight together
+    const int E4 = E / 4;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < E4; j += gridDim.x * 256) {
+        const int4 v = reinterpret_cast<const int4 *>(out_dst)[j];
+        const uint8_t f0 = active[v.x], f1 = active[v.y], f2 = active[v.z], f3 = active[v.w];
+        int4 o;
+        o.x = (f0 || park < 0) ? v.x : park, o.y = (f1 || park < 0) ? v.y : park;
+        o.z = (f2 || park < 0) ? v.z : park, o.w = (f3 || park < 0) ? v.w : park;
+        reinterpret_cast<int4 *>(eff)[j] = o;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < E - E4 * 4) {
+        const int j = E4 * 4 + threadIdx.x;
+        const int v = out_dst[j];
+        eff[j] = (active[v] || park < 0) ? v : park;
+    }
+}
+__device__ __forceinline__ bool dst_on(const BwdArgs &a, int v) { return !a.active || a.active[v] != 0; }
 
 // ---- node adjoint: d_pre = d_out * PReLU'(pre), column sums (bias gradient), slope gradient ---
 template <int H, int LPH>
@@ -564,7 +602,7 @@ __global__ __launch_bounds__(256) void k_bwd_dst_light(BwdArgs a, int C) {
         if (e - b > a.pin.light_max) continue;
         DstSums<H> s;
         dst_zero<H>(s);
-        if (e - b > 0) {
+        if (e - b > 0 && dst_on(a, v)) {
             int i = b + q;
             for (; i + W < e; i += 2 * W) {  // two rounds per trip: four independent gathers in flight
                 const PairVec<H> p0 = ld_pairs<H>(a.pairs, a.in_pos[i]), p1 = ld_pairs<H>(a.pairs, a.in_pos[i + W]);
@@ -596,7 +634,8 @@ __global__ __launch_bounds__(256) void k_bwd_dst_heavy1(BwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int c = xcd_chunk(threadIdx.x >> 6);
     if (c >= a.pin.n_chunks) return;
-    const int beg = a.pin.chunk_beg[c], end = a.pin.chunk_end[c];
+    const int beg = a.pin.chunk_beg[c];
+    const int end = dst_on(a, a.pin.heavy_node[a.pin.chunk_node[c]]) ? a.pin.chunk_end[c] : beg;
     DstSums<H> s;
     dst_zero<H>(s);
     for (int i = beg + lane; i < end; i += 64) {
@@ -867,6 +906,7 @@ size_t magic_gat_bwd_workspace_bytes(int32_t N, int32_t E, int32_t n_chunks_in, 
          align_up((size_t)(n_chunks_out > 0 ? n_chunks_out : 1) * H * f);
     b += align_up(gt * (size_t)(e_dim > 0 ? e_dim : 1) * H * f);
     b += align_up(En * H * 2 * f) + align_up(En * H * f) + align_up((size_t)N * H * f);
+    b += align_up(En * sizeof(int32_t));  // rewritten destination ids (magic_gat_bwd_active)
     return b + 256;
 }
 
@@ -878,7 +918,7 @@ static int gat_bwd_run(int32_t N, int32_t E, int32_t H, int32_t D, const magic_p
                        const float *act_out, int64_t ld_act, const float *prelu_w, const float *d_out, int64_t ld_dout,
                        float *d_pre, int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table, float *d_logit,
                        float *d_bias, float *d_prelu_w, void *workspace, size_t workspace_bytes, void *stream_,
-                       const magic_coded_input *ci) {
+                       const magic_coded_input *ci, const uint8_t *dst_active) {
     using namespace magic;
     if (N < 0 || E < 0 || H <= 0 || D <= 0) return MAGIC_ERR_INVALID_ARG;
     if (!shape_supported(H, D)) return MAGIC_ERR_UNSUPPORTED;
@@ -949,8 +989,17 @@ static int gat_bwd_run(int32_t N, int32_t E, int32_t H, int32_t D, const magic_p
     a.pairs = ar.take<float>(En * H * 2);
     a.dl_csr = ar.take<float>(En * H);
     a.delta = ar.take<float>((size_t)N * H);
+    int32_t *dst_eff = dst_active ? ar.take<int32_t>(En) : nullptr;
     if (!ar.ok()) return MAGIC_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
+    a.active = dst_active;
+    if (dst_active && d_logit) return MAGIC_ERR_UNSUPPORTED;
+    if (dst_active && E > 0) {
+        if ((uintptr_t)out_dst & 15) return MAGIC_ERR_INVALID_ARG;
+        MAGIC_LAUNCH("gat_bwd_active_dst", k_active_dst, stride_grid((E + 3) / 4, 256, 4096), 256, 0, stream, (int)N, (int)E,
+                     out_dst, dst_active, dst_eff);
+        a.out_dst = dst_eff;
+    }
     const int lph = D / 4;
     a.ci = CodedIn{nullptr, nullptr, 0, C};
     if (ci) {
@@ -980,7 +1029,22 @@ int magic_gat_bwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
                   float *d_bias, float *d_prelu_w, void *workspace, size_t workspace_bytes, void *stream_) {
     return gat_bwd_run(N, E, H, D, in_plan, in_pos, out_plan, out_dst, out_pos, hs, ld_hs, eh, ld_score, stat, ee_table,
                        etype_csr, ee_csc, e_dim, slope, pre, act_out, ld_act, prelu_w, d_out, ld_dout, d_pre, ld_dpre,
-                       d_y, ld_dy, d_ee_table, d_logit, d_bias, d_prelu_w, workspace, workspace_bytes, stream_, nullptr);
+                       d_y, ld_dy, d_ee_table, d_logit, d_bias, d_prelu_w, workspace, workspace_bytes, stream_, nullptr,
+                       nullptr);
+}
+
+int magic_gat_bwd_active(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_pos,
+                         const magic_plan *out_plan, const int32_t *out_dst, const int32_t *out_pos, const float *hs,
+                         int64_t ld_hs, const float *eh, int64_t ld_score, const float *stat, const float *ee_table,
+                         const int32_t *etype_csr, const float *ee_csc, int32_t e_dim, float slope, const float *pre,
+                         const float *act_out, int64_t ld_act, const float *prelu_w, const float *d_out,
+                         int64_t ld_dout, float *d_pre, int64_t ld_dpre, float *d_y, int64_t ld_dy, float *d_ee_table,
+                         float *d_bias, float *d_prelu_w, const uint8_t *dst_active, void *workspace,
+                         size_t workspace_bytes, void *stream_) {
+    return gat_bwd_run(N, E, H, D, in_plan, in_pos, out_plan, out_dst, out_pos, hs, ld_hs, eh, ld_score, stat, ee_table,
+                       etype_csr, ee_csc, e_dim, slope, pre, act_out, ld_act, prelu_w, d_out, ld_dout, d_pre, ld_dpre,
+                       d_y, ld_dy, d_ee_table, nullptr, d_bias, d_prelu_w, workspace, workspace_bytes, stream_, nullptr,
+                       dst_active);
 }
 
 int magic_gat_bwd_coded(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_pos,
@@ -993,7 +1057,8 @@ int magic_gat_bwd_coded(int32_t N, int32_t E, int32_t H, int32_t D, const magic_
     if (!input) return MAGIC_ERR_INVALID_ARG;
     return gat_bwd_run(N, E, H, D, in_plan, in_pos, out_plan, out_dst, out_pos, nullptr, 0, nullptr, 0, stat, ee_table,
                        etype_csr, nullptr, e_dim, slope, pre, act_out, ld_act, prelu_w, d_out, ld_dout, d_pre, ld_dpre,
-                       d_y, ld_dy, d_ee_table, nullptr, d_bias, d_prelu_w, workspace, workspace_bytes, stream_, input);
+                       d_y, ld_dy, d_ee_table, nullptr, d_bias, d_prelu_w, workspace, workspace_bytes, stream_, input,
+                       nullptr);
 }
 
 }  // extern "C"

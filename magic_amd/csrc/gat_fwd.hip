@@ -44,7 +44,13 @@ struct FwdArgs {
     float *ws_acc;    // [n_chunks * agg_split,C]
     int agg_split;    // waves that share one chunk in the aggregation (graphs with few chunks)
     CodedIn ci;       // coded layer input (the CODED kernels): replaces hs, eh, et and res
+    const uint8_t *active;  // [N] 1 = the output row of this destination is wanted; null = all of them
 };
+
+// A destination whose output nobody reads (the decoder's rows outside the masked set) is treated as a node without
+// in-edges: none of its edges is visited, its output row is bias (+ residual) and its log-sum-exp +inf, which makes
+// every attention weight recomputed from it in backward an exact zero.
+__device__ __forceinline__ bool dst_on(const FwdArgs &a, int v) { return !a.active || a.active[v] != 0; }
 
 // A chunk is 256 edges, taken four gathered rows at a time by one wave: a graph with few heavy edges leaves
 // most of the chip idle behind 64 dependent round trips per wave.  Below ~1,500 chunks every chunk is cut
@@ -159,12 +165,13 @@ __global__ __launch_bounds__(256) void k_fwd_light(FwdArgs a) {
         // walk nodes by segment length when a node row is wide enough to stand alone in memory
         const int v = (G >= 8 && a.plan.order) ? a.plan.order[vi] : vi;
         const int b = a.plan.ptr[v], e = a.plan.ptr[v + 1];
-        const int deg = e - b;
-        if (deg > a.plan.light_max) continue;
+        if (e - b > a.plan.light_max) continue;
+        const bool on = dst_on(a, v);
+        const int deg = on ? e - b : 0;
         const uint32_t cv = CODED ? a.ci.code[v] : 0u;
         const float etv = CODED ? coded1(a.ci, cv, C + H + h) : a.et[(int64_t)v * a.ld_s + h];
         float4 acc = f4zero();
-        float lse = 0.f;
+        float lse = on ? 0.f : INFINITY;
         if (NSUB == 1 && deg > 0 && deg <= 4) {
             float x[4], l[4], p[4];
             float4 r[4];
@@ -319,6 +326,7 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_stats(FwdArgs a) {
     if (c >= a.plan.n_chunks) return;
     const int beg = a.plan.chunk_beg[c], end = a.plan.chunk_end[c];
     const int v = a.plan.heavy_node[a.plan.chunk_node[c]];
+    if (!dst_on(a, v)) return;
     float m[H], s[H], etv[H];
     if (CODED) coded_heads<H>(a.ci, a.ci.code[v], a.ci.C + H, etv);
 #pragma unroll
@@ -415,6 +423,11 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_agg(FwdArgs a) {
         beg = min(beg + run * per, end);
         end = min(beg + per, end);
     }
+    if (!dst_on(a, a.plan.heavy_node[slot])) {  // no statistics were formed: only the log-sum-exp is recorded
+        if (a.stat && c == a.plan.heavy_cptr[slot] && run == 0 && lane < H)
+            *reinterpret_cast<float2 *>(a.stat + ((int64_t)a.plan.heavy_node[slot] * H + lane) * 2) = make_float2(0.f, INFINITY);
+        return;
+    }
     float mm[H], ss[H];
     node_stats<H>(a, slot, lane, mm, ss);
     const int g = lane % G, sg = lane / G, h = g / LPH;
@@ -476,7 +489,8 @@ __global__ __launch_bounds__(256) void k_fwd_heavy_finish(FwdArgs a) {
     const int g = threadIdx.x % G, sg = threadIdx.x / G;
     const int c0 = a.plan.heavy_cptr[slot] * a.agg_split, c1 = a.plan.heavy_cptr[slot + 1] * a.agg_split;
     float4 acc = f4zero();
-    for (int c = c0 + sg; c < c1; c += NSGB) add4(acc, ld4(a.ws_acc + (int64_t)c * C + g * 4));
+    if (dst_on(a, a.plan.heavy_node[slot]))
+        for (int c = c0 + sg; c < c1; c += NSGB) add4(acc, ld4(a.ws_acc + (int64_t)c * C + g * 4));
     part[threadIdx.x] = acc;
     __syncthreads();
     if (sg == 0) {
@@ -522,7 +536,7 @@ static int gat_fwd_run(int32_t N, int32_t E, int32_t H, int32_t D, const magic_p
                        float slope, const float *bias, const float *res, int64_t ld_res, const uint8_t *res_mask,
                        float res_scale, const float *prelu_w, float *out, int64_t ld_out, float *pre, float *attn,
                        float *stat, void *workspace, size_t workspace_bytes, void *stream_,
-                       const magic_coded_input *ci) {
+                       const magic_coded_input *ci, const uint8_t *dst_active) {
     using namespace magic;
     if (N < 0 || E < 0 || H <= 0 || D <= 0) return MAGIC_ERR_INVALID_ARG;
     if (!shape_supported(H, D)) return MAGIC_ERR_UNSUPPORTED;
@@ -538,6 +552,7 @@ static int gat_fwd_run(int32_t N, int32_t E, int32_t H, int32_t D, const magic_p
         res = nullptr;
     }
     if (!hs || !eh || !et) return MAGIC_ERR_INVALID_ARG;
+    if (dst_active && attn) return MAGIC_ERR_UNSUPPORTED;  // (the edges of an unwanted destination are not visited)
     if (E > 0 && !in_src) return MAGIC_ERR_INVALID_ARG;
     if (in_plan->light_max > magic::SEG) return MAGIC_ERR_UNSUPPORTED;  // a lane group's strip holds SEG edges
     const bool table = ee_table != nullptr;
@@ -574,6 +589,7 @@ static int gat_fwd_run(int32_t N, int32_t E, int32_t H, int32_t D, const magic_p
     a.stat = stat;
     a.ws_stats = a.ws_acc = nullptr;
     a.agg_split = agg_split_for(a.plan.n_chunks);
+    a.active = dst_active;
     a.ci = CodedIn{nullptr, nullptr, 0, C};
     if (ci) a.ci = CodedIn{ci->code, ci->table, (int)ci->ld_table, C};
     Arena ar(workspace, workspace_bytes);
@@ -610,7 +626,19 @@ int magic_gat_fwd(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *
                   size_t workspace_bytes, void *stream_) {
     return gat_fwd_run(N, E, H, D, in_plan, in_src, in_dst, hs, ld_hs, eh, et, ld_score, ee_table, etype_csc, ee_csc,
                        slope, bias, res, ld_res, res_mask, res_scale, prelu_w, out, ld_out, pre, attn, stat, workspace,
-                       workspace_bytes, stream_, nullptr);
+                       workspace_bytes, stream_, nullptr, nullptr);
+}
+
+int magic_gat_fwd_active(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_src,
+                         const int32_t *in_dst, const float *hs, int64_t ld_hs, const float *eh, const float *et,
+                         int64_t ld_score, const float *ee_table, const int32_t *etype_csc, const float *ee_csc,
+                         float slope, const float *bias, const float *res, int64_t ld_res, const uint8_t *res_mask,
+                         float res_scale, const float *prelu_w, float *out, int64_t ld_out, float *pre, float *attn,
+                         float *stat, const uint8_t *dst_active, void *workspace, size_t workspace_bytes,
+                         void *stream_) {
+    return gat_fwd_run(N, E, H, D, in_plan, in_src, in_dst, hs, ld_hs, eh, et, ld_score, ee_table, etype_csc, ee_csc,
+                       slope, bias, res, ld_res, res_mask, res_scale, prelu_w, out, ld_out, pre, attn, stat, workspace,
+                       workspace_bytes, stream_, nullptr, dst_active);
 }
 
 int magic_gat_fwd_coded(int32_t N, int32_t E, int32_t H, int32_t D, const magic_plan *in_plan, const int32_t *in_src,
@@ -620,7 +648,7 @@ int magic_gat_fwd_coded(int32_t N, int32_t E, int32_t H, int32_t D, const magic_
     if (!input) return MAGIC_ERR_INVALID_ARG;
     return gat_fwd_run(N, E, H, D, in_plan, in_src, nullptr, nullptr, 0, nullptr, nullptr, 0, ee_table, etype_csc,
                        nullptr, slope, bias, nullptr, 0, nullptr, 1.f, prelu_w, out, ld_out, pre, nullptr, stat,
-                       workspace, workspace_bytes, stream_, input);
+                       workspace, workspace_bytes, stream_, input, nullptr);
 }
 
 }  // extern "C"

@@ -138,6 +138,10 @@ class GMAEModel(nn.Module):
         # run the first encoder layer on code words (node type, masked, dropout bits) when the input is known to
         # be one-hot node types; MAGIC_CODED_INPUT=0 (or this attribute) keeps the dense projection instead
         self.coded_input = os.environ.get("MAGIC_CODED_INPUT", "1") != "0"
+        # decoder sweeps restricted to the rows the loss reads (MAGIC_DECODER_ROWS=0: every row, as the reference)
+        self.decoder_rows = os.environ.get("MAGIC_DECODER_ROWS", "1") != "0"
+        # (a smaller graph's node rows are served from the caches whichever edges are visited: nothing to gain there)
+        self.decoder_rows_min_nodes = 200_000
         self._mask_rate = mask_rate
         self._output_hidden_size = hidden_dim
         self._alpha_l = alpha_l
@@ -327,6 +331,11 @@ class GMAEModel(nn.Module):
                 params += [w_aug, table, bias, layer.activation.weight]
             params.append(self.encoder_to_decoder.weight)
             params += list(folded[-1])
+            if (self.decoder_rows and not return_parts and len(mask_nodes) < g.num_nodes()
+                    and g.num_nodes() >= self.decoder_rows_min_nodes):
+                # only recon[mask_nodes] is read below (autoencoder.py:242-245): the decoder skips the other rows
+                cfg.recon_rows = torch.zeros(g.num_nodes(), dtype=torch.uint8, device=g.device)
+                cfg.recon_rows.index_fill_(0, mask_nodes, 1)
             if feat_has_grad:
                 enc_rep, recon_p, samples = FusedGMAEFn.apply(pre_use_x, sample_idx, cfg, None, *params)
             else:

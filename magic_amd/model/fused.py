@@ -50,6 +50,9 @@ class FusedCfg:
         # layer then runs on code words (type, masked, dropout keep bits) and a [n_dim, M] table instead of a
         # projected [N, C] array -- no projection launch, no gathers of 4C-byte rows, no [N, n_dim] operand
         self.node_types = node_types
+        # uint8 [N]: the rows of the reconstruction the caller reads (the masked nodes of the loss); the decoder's
+        # sweeps then visit the edges into those rows only.  None: every row is produced.
+        self.recon_rows = None
 
     def coded(self, token) -> bool:
         return (self.node_types is not None and token is not None and self.res_kinds[0] == "linear" and self.H == 4
@@ -113,7 +116,7 @@ class FusedGMAEFn(torch.autograd.Function):
         hs_d, score_d, _ = ops.proj_fwd(rep, w_aug_d, cfg.Dp, 2, 0, x_mask=mask_d, x_scale=cfg.scale)
         recon, _, _, stat_d = ops.gat_fwd(s, 1, cfg.Dp, hs_d, score_d[:, :1], score_d[:, 1:], table_d.contiguous(),
                                           cfg.etype, None, cfg.slope, bias_d, None, None, False, want_attn=False,
-                                          want_stat=True)
+                                          want_stat=True, dst_active=cfg.recon_rows)
         samples = enc[sample_idx]
         ctx.cfg = cfg
         ctx.coded = coded
@@ -147,7 +150,8 @@ class FusedGMAEFn(torch.autograd.Function):
         d_y = _aligned_rows(N, Dp + 2, dev)
         table_d = params[4 * L + 2].contiguous()
         d_table, _, d_bias, _ = ops.gat_bwd(s, 1, Dp, hs_d, score_d[:, :1], stat_d, table_d, cfg.etype_csr, None,
-                                             cfg.e_dim, cfg.slope, None, None, None, d_recon, d_recon, d_y, True)
+                                             cfg.e_dim, cfg.slope, None, None, None, d_recon, d_recon, d_y, True,
+                                             dst_active=cfg.recon_rows)
         grads[4 * L + 1] = ops.proj_bwd_weight(d_y, rep, x_mask=mask_d, x_scale=cfg.scale)
         grads[4 * L + 2] = d_table
         grads[4 * L + 3] = d_bias

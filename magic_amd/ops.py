@@ -144,17 +144,18 @@ def _struct_in(n_nodes, plan7, in_src, in_dst):
 
 def _gat_fwd_(p0, p1, p2, p3, p4, p5, p6, p7, in_src, in_dst, n_heads: int, head_dim: int, hs, eh, et, ee_table,
               etype_csc, ee_csc, slope: float, bias, res, prelu_w, want_pre: bool, res_mask, res_scale: float,
-              want_attn: bool, want_stat: bool, out):
+              want_attn: bool, want_stat: bool, dst_active, out):
     s = _struct_in(out.shape[0], (p0, p1, p2, p3, p4, p5, p6, p7), in_src, in_dst)
     _, pre, attn, stat = _lib.gat_fwd(s, n_heads, head_dim, hs, eh, et, ee_table, etype_csc, ee_csc, slope, bias, res,
                                       prelu_w, want_pre, res_mask=res_mask, res_scale=res_scale, out=out,
-                                      want_attn=want_attn, want_stat=want_stat)
+                                      want_attn=want_attn, want_stat=want_stat, dst_active=dst_active)
     e = _empty(hs)
     return pre if pre is not None else e, attn if attn is not None else e, stat if stat is not None else e
 
 
 def _gat_fwd__fake(p0, p1, p2, p3, p4, p5, p6, p7, in_src, in_dst, n_heads, head_dim, hs, eh, et, ee_table, etype_csc,
-                   ee_csc, slope, bias, res, prelu_w, want_pre, res_mask, res_scale, want_attn, want_stat, out):
+                   ee_csc, slope, bias, res, prelu_w, want_pre, res_mask, res_scale, want_attn, want_stat, dst_active,
+                   out):
     n, c = out.shape[0], n_heads * head_dim
     return (hs.new_empty((n, c) if want_pre else (0,)),
             hs.new_empty((in_src.shape[0], n_heads) if want_attn else (0,)),
@@ -164,17 +165,18 @@ def _gat_fwd__fake(p0, p1, p2, p3, p4, p5, p6, p7, in_src, in_dst, n_heads, head
 _register("gat_fwd_", "(" + _PLAN.format("in_") + ", Tensor in_src, Tensor in_dst, int n_heads, int head_dim, "
           "Tensor hs, Tensor eh, Tensor et, Tensor? ee_table, Tensor? etype_csc, Tensor? ee_csc, float slope, "
           "Tensor? bias, Tensor? res, Tensor? prelu_w, bool want_pre, Tensor? res_mask, float res_scale, "
-          "bool want_attn, bool want_stat, Tensor(a!) out) -> (Tensor, Tensor, Tensor)", _gat_fwd_, _gat_fwd__fake)
+          "bool want_attn, bool want_stat, Tensor? dst_active, Tensor(a!) out) -> (Tensor, Tensor, Tensor)",
+          _gat_fwd_, _gat_fwd__fake)
 
 
 def _gat_bwd_(i0, i1, i2, i3, i4, i5, i6, i7, o0, o1, o2, o3, o4, o5, o6, o7, in_pos, out_dst, out_pos, n_heads: int,
               head_dim: int, hs, eh, stat, ee_table, etype_csr, ee_csc, e_dim: int, slope: float, pre, act_out,
-              prelu_w, d_out, d_pre, d_y, want_bias: bool, want_dlogit: bool):
+              prelu_w, d_out, d_pre, d_y, want_bias: bool, want_dlogit: bool, dst_active):
     s = SimpleNamespace(num_nodes=hs.shape[0], num_edges=int(out_dst.numel()), plan_in=_plan(i0, i1, i2, i3, i4, i5, i6, i7),
                         plan_out=_plan(o0, o1, o2, o3, o4, o5, o6, o7), in_pos=in_pos, out_dst=out_dst, out_pos=out_pos)
     d_table, d_logit, d_bias, d_prelu = _lib.gat_bwd(s, n_heads, head_dim, hs, eh, stat, ee_table, etype_csr, ee_csc,
                                                      e_dim, slope, pre, act_out, prelu_w, d_out, d_pre, d_y,
-                                                     want_bias, want_dlogit)
+                                                     want_bias, want_dlogit, dst_active=dst_active)
     e = _empty(hs)
     return (d_table if d_table is not None else e, d_logit if d_logit is not None else e,
             d_bias if d_bias is not None else e, d_prelu if d_prelu is not None else e)
@@ -182,7 +184,7 @@ def _gat_bwd_(i0, i1, i2, i3, i4, i5, i6, i7, o0, o1, o2, o3, o4, o5, o6, o7, in
 
 def _gat_bwd__fake(i0, i1, i2, i3, i4, i5, i6, i7, o0, o1, o2, o3, o4, o5, o6, o7, in_pos, out_dst, out_pos, n_heads,
                    head_dim, hs, eh, stat, ee_table, etype_csr, ee_csc, e_dim, slope, pre, act_out, prelu_w, d_out,
-                   d_pre, d_y, want_bias, want_dlogit):
+                   d_pre, d_y, want_bias, want_dlogit, dst_active):
     return (hs.new_empty((e_dim, n_heads) if ee_table is not None else (0,)),
             hs.new_empty((out_dst.shape[0], n_heads) if want_dlogit else (0,)),
             hs.new_empty(n_heads * head_dim if want_bias else 0), hs.new_empty(1 if prelu_w is not None else 0))
@@ -192,12 +194,13 @@ def _gat_bwd__fake(i0, i1, i2, i3, i4, i5, i6, i7, o0, o1, o2, o3, o4, o5, o6, o
 _register("gat_bwd_", "(" + _PLAN.format("in_") + ", " + _PLAN.format("out_") + ", Tensor in_pos, Tensor out_dst, "
           "Tensor out_pos, int n_heads, int head_dim, Tensor hs, Tensor eh, Tensor stat, Tensor? ee_table, "
           "Tensor? etype_csr, Tensor? ee_csc, int e_dim, float slope, Tensor? pre, Tensor? act_out, "
-          "Tensor? prelu_w, Tensor(a!) d_out, Tensor(b!) d_pre, Tensor(c!) d_y, bool want_bias, bool want_dlogit) "
+          "Tensor? prelu_w, Tensor(a!) d_out, Tensor(b!) d_pre, Tensor(c!) d_y, bool want_bias, bool want_dlogit, "
+          "Tensor? dst_active) "
           "-> (Tensor, Tensor, Tensor, Tensor)", _gat_bwd_, _gat_bwd__fake)
 
 
 def gat_fwd(struct, H, D, hs, eh, et, ee_table, etype_csc, ee_csc, slope, bias, res, prelu_w, want_pre,
-            res_mask=None, res_scale=1.0, out=None, want_attn=True, want_stat=False):
+            res_mask=None, res_scale=1.0, out=None, want_attn=True, want_stat=False, dst_active=None):
     """``torch.ops.magic.gat_fwd_`` with the calling convention of ``_lib.gat_fwd`` (graph structure
     object in, ``None`` for absent outputs): returns (out, pre, attn, stat)."""
     if out is None:
@@ -205,16 +208,16 @@ def gat_fwd(struct, H, D, hs, eh, et, ee_table, etype_csc, ee_csc, slope, bias, 
     pre, attn, stat = torch.ops.magic.gat_fwd_(
         *plan_tensors(struct.plan_in), struct.in_src, struct.in_dst, H, D, hs, eh, et, ee_table, etype_csc, ee_csc,
         float(slope), bias, res, prelu_w, bool(want_pre), res_mask, float(res_scale), bool(want_attn),
-        bool(want_stat), out)
+        bool(want_stat), dst_active, out)
     return out, _none(pre), _none(attn), _none(stat)
 
 
 def gat_bwd(struct, H, D, hs, eh, stat, ee_table, etype_csr, ee_csc, e_dim, slope, pre, act_out, prelu_w, d_out,
-            d_pre, d_y, want_bias, want_dlogit=False):
+            d_pre, d_y, want_bias, want_dlogit=False, dst_active=None):
     d_table, d_logit, d_bias, d_prelu = torch.ops.magic.gat_bwd_(
         *plan_tensors(struct.plan_in), *plan_tensors(struct.plan_out), struct.in_pos, struct.out_dst, struct.out_pos,
         H, D, hs, eh, stat, ee_table, etype_csr, ee_csc, int(e_dim), float(slope), pre, act_out, prelu_w, d_out,
-        d_pre, d_y, bool(want_bias), bool(want_dlogit))
+        d_pre, d_y, bool(want_bias), bool(want_dlogit), dst_active)
     return _none(d_table), _none(d_logit), _none(d_bias), _none(d_prelu)
 
 

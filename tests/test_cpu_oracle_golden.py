@@ -430,12 +430,12 @@ def test_custom_ops_are_registered_with_schemas_and_fake_kernels():
         out = f(n, h * d)
         pre, attn, stat = torch.ops.magic.gat_fwd_(*plan, torch.empty(e, **i32), torch.empty(e, **i32), h, d,
                                                    f(n, h * d), f(n, h), f(n, h), f(17, h), torch.empty(e, **i32),
-                                                   None, 0.2, f(h * d), None, f(1), True, None, 1.0, True, True, out)
+                                                   None, 0.2, f(h * d), None, f(1), True, None, 1.0, True, True, None, out)
         assert pre.shape == (n, h * d) and attn.shape == (e, h) and stat.shape == (n, h, 2)
         d_table, d_logit, d_bias, d_prelu = torch.ops.magic.gat_bwd_(
             *plan, *plan, torch.empty(e, **i32), torch.empty(e, **i32), torch.empty(e, **i32), h, d, f(n, h * d),
             f(n, h), stat, f(17, h), torch.empty(e, **i32), None, 17, 0.2, None, None, None, f(n, h * d), f(n, h * d),
-            f(n, h * d + 2 * h), True, False)
+            f(n, h * d + 2 * h), True, False, None)
         assert d_table.shape == (17, h) and d_logit.numel() == 0 and d_bias.shape == (h * d,) and d_prelu.numel() == 0
         ptrs = torch.ops.magic.csr_build(torch.empty(e, dtype=torch.int64, device=dev),
                                          torch.empty(e, dtype=torch.int64, device=dev), n)

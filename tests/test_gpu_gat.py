@@ -460,7 +460,7 @@ def test_custom_operators_called_directly(cuda):
     out = torch.empty(n, H * D, device=cuda)
     pre, attn, stat = torch.ops.magic.gat_fwd_(*ops.plan_tensors(s.plan_in), s.in_src, s.in_dst, H, D, hs, eh, et,
                                                table, g.edge_types_csc(), None, 0.2, bias, None, None, False, None,
-                                               1.0, True, True, out)
+                                               1.0, True, True, None, out)
     assert pre.numel() == 0 and attn.shape == (src.size, H) and stat.shape == (n, H, 2)
     # oracle statement of model/gat.py:302-324 on the same operands
     S, T = torch.from_numpy(src), torch.from_numpy(dst)
@@ -629,3 +629,100 @@ def test_fold_of_all_layers_in_one_launch_equals_the_per_layer_calls(cuda):
         assert len(out) == len(single) == 7
         for a, b in zip(out, single):
             assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), i
+
+
+@pytest.mark.parametrize("H,D", [(1, 8), (1, 16), (4, 16), (4, 64)])
+@pytest.mark.parametrize("hub_on", [False, True])
+def test_sweeps_restricted_to_marked_destinations(H, D, hub_on, cuda):
+    """magic_gat_fwd_active / magic_gat_bwd_active (the decoder, whose output is read at the masked rows only,
+    model/autoencoder.py:240-245): marked rows bit for bit those of the full sweeps, unmarked rows = bias with a
+    +inf log-sum-exp; with a gradient that is zero outside the marked rows every backward output equals the
+    full backward's."""
+    from magic_amd import ops
+    n, e, n_dim, e_dim = 3000, 30000, 5, 17
+    src, dst, ntype, etype = small_graph(n, e, n_dim, e_dim, seed=21, hub_deg=700, hub_out=400)
+    g = to_graph(src, dst, n, ntype, etype, n_dim, e_dim, cuda)
+    s = g.structure.ensure_csr()
+    assert s.plan_in.n_chunks > 3 and s.plan_out.n_chunks > 0
+    torch.manual_seed(8)
+    C = H * D
+    hs = torch.randn(n, C, device=cuda)
+    eh, et = torch.randn(n, H, device=cuda), torch.randn(n, H, device=cuda)
+    table = torch.randn(e_dim, H, device=cuda)
+    bias = torch.randn(C, device=cuda)
+    flags = (torch.rand(n) < 0.5).to(torch.uint8)
+    flags[3] = int(hub_on)          # the hub of small_graph
+    flags[:2] = 1                   # (the node the unmarked edges are pointed at is not node 0)
+    flags = flags.to(cuda)
+    on = flags.bool()
+
+    def fwd(active):
+        return ops.gat_fwd(s, H, D, hs, eh, et, table, g.edge_types_csc(), None, 0.2, bias, None, None, False,
+                           want_attn=False, want_stat=True, dst_active=active)
+    out_all, _, _, stat_all = fwd(None)
+    out_on, _, _, stat_on = fwd(flags)
+    assert torch.equal(out_on[on], out_all[on]) and torch.equal(stat_on[on], stat_all[on])
+    assert torch.equal(out_on[~on], bias.expand(int((~on).sum()), C))
+    assert torch.isinf(stat_on[~on][:, :, 1]).all() and (stat_on[~on][:, :, 1] > 0).all()
+
+    d_out = torch.randn(n, C, device=cuda) * on[:, None]
+
+    def bwd(stat, active):
+        d = d_out.clone()
+        d_y = torch.full((n, (C + 2 * H + 3) // 4 * 4), float("nan"), device=cuda)[:, :C + 2 * H]   # float4 rows
+        d_table, _, d_bias, _ = ops.gat_bwd(s, H, D, hs, eh, stat, table, g.edge_types_csr(), None, e_dim, 0.2, None,
+                                            None, None, d, d, d_y, True, dst_active=active)
+        return d_y.contiguous(), d_table, d_bias
+    ref = bwd(stat_all, None)
+    for stat in (stat_on, stat_all):     # (the statistics of either forward serve)
+        got = bwd(stat, flags)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    # all marked / none marked
+    ones = torch.ones(n, dtype=torch.uint8, device=cuda)
+    assert torch.equal(fwd(ones)[0], out_all)
+    for a, b in zip(bwd(stat_all, ones), ref):
+        assert torch.equal(a, b)
+    zeros = torch.zeros(n, dtype=torch.uint8, device=cuda)
+    assert torch.equal(fwd(zeros)[0], bias.expand(n, C))
+    with pytest.raises(Exception):
+        ops.gat_fwd(s, H, D, hs, eh, et, table, g.edge_types_csc(), None, 0.2, bias, None, None, False,
+                    want_attn=True, dst_active=flags)
+
+
+@pytest.mark.parametrize("shape", [(5, 17, 64, 3), (8, 20, 256, 2)])
+def test_decoder_restricted_to_the_masked_rows_changes_nothing(cuda, shape):
+    """compute_loss reads recon[mask_nodes] only (model/autoencoder.py:242-245): with the decoder's sweeps restricted
+    to those rows the loss and every parameter gradient are bit for bit those of the full decoder."""
+    from magic_amd import _lib
+    n_dim, e_dim, hidden, layers = shape
+    n, e = 1500, 12000
+    src, dst, ntype, etype = small_graph(n, e, n_dim, e_dim, seed=41, hub_deg=500, hub_out=300)
+    _, mine = _model_pair(n_dim, e_dim, hidden, layers, cuda)
+    mine.train()
+    gen = torch.Generator().manual_seed(3)
+    widths = [n_dim] + [hidden] * (layers - 1) + [hidden]
+    drop = [(torch.rand(n, w, generator=gen) < 0.9).to(cuda) for w in widths]
+    perm = torch.randperm(n, generator=gen).to(cuda)
+    pos_idx = torch.randperm(src.size, generator=gen)[:n]
+    neg = (torch.randint(0, n, (n,), generator=gen), torch.randint(0, n, (n,), generator=gen))
+    outs = []
+    mine.decoder_rows_min_nodes = 0
+    for rows in (True, False):
+        mine.decoder_rows = rows
+        g = to_graph(src, dst, n, ntype, etype, n_dim, e_dim, cuda)
+        mine.zero_grad(set_to_none=True)
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        loss = mine.compute_loss(g, perm=perm, pos_idx=pos_idx, neg_pairs=neg, drop_masks=drop)
+        loss.backward()
+        _lib.prof_enable(False)
+        names = set(_lib.prof_read(200))
+        _lib.prof_reset()
+        assert ("gat_bwd_active_dst" in names) == rows, names
+        outs.append((loss.detach().clone(), {k: p.grad.clone() for k, p in mine.named_parameters() if p.grad is not None}))
+    mine.decoder_rows = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert set(outs[0][1]) == set(outs[1][1])
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k

@@ -72,6 +72,15 @@ int main() {
                          0.2f, nullptr, nullptr, 0, nullptr, 1.f, nullptr, nullptr, 64, nullptr, nullptr, nullptr, nullptr,
                          0, nullptr),
            MAGIC_ERR_INVALID_ARG);
+    // sweeps restricted to marked destinations: the attention output is refused, a missing plan too
+    EXPECT(magic_gat_fwd_active(4, 4, 4, 16, nullptr, nullptr, nullptr, nullptr, 64, nullptr, nullptr, 8, nullptr, nullptr,
+                                nullptr, 0.2f, nullptr, nullptr, 0, nullptr, 1.f, nullptr, nullptr, 64, nullptr, nullptr,
+                                nullptr, (const uint8_t *)dummy, nullptr, 0, nullptr),
+           MAGIC_ERR_INVALID_ARG);
+    EXPECT(magic_gat_bwd_active(4, 4, 4, 16, nullptr, nullptr, nullptr, nullptr, nullptr, dummy, 64, dummy, 4, dummy, dummy,
+                                nullptr, nullptr, 17, 0.2f, nullptr, nullptr, 0, nullptr, dummy, 64, dummy, 64, dummy, 72,
+                                nullptr, nullptr, nullptr, (const uint8_t *)dummy, nullptr, 0, nullptr),
+           MAGIC_ERR_INVALID_ARG);
     // coded first-layer input
     if (magic_coded_table_rows(5) != 5 + 1 + 32 || magic_coded_table_rows(MAGIC_CODED_MAX_DIM + 1) != 0) ++failures;
     EXPECT(magic_coded_table(0, 136, dummy, 5, dummy, 1.f, dummy, 136, nullptr), MAGIC_ERR_INVALID_ARG);
