@@ -121,6 +121,18 @@ def sweep_bytes(kind, N, E_seg, E_all, H, C, res):
         stat, stat_tab = E_seg * 8 * H, N * 8 * H
         stream = E_seg * (8 + 8 * H) + N * (8 + 4 * H + 2 * row)
         return stream + g + stat, stream + once(g) + min(stat, stat_tab), g, table
+    if kind == "fwd_coded":
+        # first layer on code words: the projected rows come out of a table of a few dozen rows that stays on the
+        # die, so per edge only the src id, the edge type and the source's 4-byte code word move; per node the
+        # segment pointer, walk order, own code word, statistics out and the output row (the residual is a table row)
+        b = E_seg * 12 + N * (12 + 8 * H + row)
+        return b, E_seg * 8 + min(E_seg, N) * 4 + N * (12 + 8 * H + row), 0, 0
+    if kind == "bwd_src_coded":
+        # as bwd_src with the node's own row and scores replaced by its code word
+        g = E_seg * row
+        stat, stat_tab = E_seg * 8 * H, N * 8 * H
+        stream = E_seg * (8 + 8 * H) + N * (12 + row)
+        return stream + g + stat, stream + once(g) + min(stat, stat_tab), g, table
     if kind == "bwd_dst":
         # per edge: CSR position, gathered (a, t) pair (every pair exactly once)
         # per node: segment pointer, walk order, delta and d_et out
@@ -236,11 +248,13 @@ def roofline_rows(prof, struct, workload, steps, n, n_dim, hidden, layers, n_pai
     lay = [(4, hidden, "linear" if (n_dim if l == 0 else hidden) != hidden else "identity")
            for l in range(layers)] + [(1, _pad_head_dim(n_dim), None)]
     sparse = {}     # template name -> list of (per_use, compulsory, gathered, table), one per launch of a step
-    for H, C, r in lay:
+    coded0 = any(k.startswith("gat_fwd_light_coded<") for k in prof)    # first layer ran on code words
+    for l, (H, C, r) in enumerate(lay):
         t = f"<{H},{C // (4 * H)}>"
-        for base, kind, e_seg in (("gat_fwd_light", "fwd", e_in),
-                                  ("gat_bwd_src_light", "bwd_src", e_out), ("gat_bwd_dst_light", "bwd_dst", e_in),
-                                  ("gat_bwd_deh_light", "bwd_deh", e_out)):
+        c = "_coded" if (l == 0 and coded0) else ""
+        for base, kind, e_seg in (("gat_fwd_light" + c, "fwd" + c, e_in),
+                                  ("gat_bwd_src_light" + c, "bwd_src" + c, e_out),
+                                  ("gat_bwd_dst_light", "bwd_dst", e_in), ("gat_bwd_deh_light", "bwd_deh", e_out)):
             sparse.setdefault(base + t, []).append(sweep_bytes(kind, n, e_seg, E, H, C, r))
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:

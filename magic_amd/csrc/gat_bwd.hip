@@ -859,9 +859,9 @@ int launch_bwd(BwdArgs &a, hipStream_t stream) {
         return st0 != MAGIC_OK ? st0 : launch_status();
     }
     if (H == 4 && LPH == 16)  // 1 KB rows: one wavefront per node
-        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_wave<TABLE, CODED>), stride_grid(a.N, 4, 256 * 5), 256, 0, stream, a);  // resident workgroups only: the pipeline fill is paid once per wavefront
+        MAGIC_LAUNCH(prof_on() ? prof_name(CODED ? "gat_bwd_src_light_coded" : "gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_wave<TABLE, CODED>), stride_grid(a.N, 4, 256 * 5), 256, 0, stream, a);  // resident workgroups only: the pipeline fill is paid once per wavefront
     else
-        MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_light<H, LPH, TABLE, CODED>), stride_grid(a.N, NPB, 256 * 16), 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name(CODED ? "gat_bwd_src_light_coded" : "gat_bwd_src_light", H, LPH) : "gat_bwd_src_light", (k_bwd_src_light<H, LPH, TABLE, CODED>), stride_grid(a.N, NPB, 256 * 16), 256, 0, stream, a);
     if (a.pout.n_chunks > 0) {
         const int cgrid = chunk_grid(a.pout.n_chunks);
         MAGIC_LAUNCH(prof_on() ? prof_name("gat_bwd_src_heavy1", H, LPH) : "gat_bwd_src_heavy1", (k_bwd_src_heavy1<H, LPH, TABLE, CODED>), cgrid, 256, 0, stream, a);

@@ -505,7 +505,7 @@ int launch_fwd(const FwdArgs &a, hipStream_t stream) {
     constexpr int NPB = 256 / (G < 8 ? 8 : G);
     if (a.N > 0) {
         int grid = stride_grid(a.N, NPB, 256 * 32);
-        MAGIC_LAUNCH(prof_on() ? prof_name("gat_fwd_light", H, LPH) : "gat_fwd_light", (k_fwd_light<H, LPH, TABLE, CODED>), grid, 256, 0, stream, a);
+        MAGIC_LAUNCH(prof_on() ? prof_name(CODED ? "gat_fwd_light_coded" : "gat_fwd_light", H, LPH) : "gat_fwd_light", (k_fwd_light<H, LPH, TABLE, CODED>), grid, 256, 0, stream, a);
     }
     if (a.plan.n_chunks > 0) {
         int cgrid = chunk_grid(a.plan.n_chunks);

@@ -80,6 +80,16 @@ def test_sweep_classification_follows_the_counters():
     per_use, comp, gath, table = bench.sweep_bytes("bwd_src", n, e, e, h, c, None)
     r = bench.classify_sweep(per_use, comp, gath, table, 882649818, 230e-6)
     assert r["bound"] == "l2-gather" and r["frac"] < 1.0 and r["peak"] == bench.L2_GATHER_PEAK_GBS
+    # first layer on code words: no gathered node rows in forward, the source sweep keeps its gradient-row gather
+    n, e, c = 700000, 3000000, 64
+    per_use, comp, gath, table = bench.sweep_bytes("fwd_coded", n, e, e, h, c, "linear")
+    assert per_use == e * 12 + n * (12 + 8 * h + 4 * c) and gath == 0 and comp <= per_use
+    assert bench.classify_sweep(per_use, comp, gath, table, 371709291, 134e-6)["bound"] == "hbm"
+    dense = bench.sweep_bytes("bwd_src", n, e, e, h, c, None)
+    coded = bench.sweep_bytes("bwd_src_coded", n, e, e, h, c, None)
+    assert coded[2] == dense[2] and dense[0] - coded[0] == n * (4 * h + 4 * c - 4)
+    n, e, c = 96000, 2040000, 256
+    per_use, comp, gath, table = bench.sweep_bytes("bwd_src", n, e, e, h, c, None)
     # no counters: the per-use rate decides
     assert bench.classify_sweep(per_use, comp, gath, table, None, 230e-6)["bound"] == "l2-gather"
     assert bench.classify_sweep(per_use, comp, gath, table, None, 400e-6)["bound"] == "hbm"

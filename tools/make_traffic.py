@@ -51,7 +51,8 @@ def projection_traffic(rd_dir, wr_dir, seq_path):
     out, lines = {}, []
     per = {}
     for ctr, directory, scale in (("FETCH_SIZE", rd_dir, 2.0), ("WRITE_SIZE", wr_dir, 1.0)):
-        d = [x for x in dispatches(directory, ctr) if x[1].startswith(PROJ_MAIN)]
+        d = [x for x in dispatches(directory, ctr)
+             if x[1].startswith(PROJ_MAIN) and not x[1].startswith("k_proj_dw_wide_reduce")]
         if not d or len(d) % p:
             lines.append(f"# projection launches: {len(d)} dispatches do not tile the {p}-launch step sequence ({ctr})")
             return {}, lines
@@ -113,13 +114,16 @@ def main():
     for k, v in traffic.items():
         base = k.split("<")[0]
         if base == "k_bwd_src_wave":    # the wavefront-per-node source sweep exists for 4 heads x 16 lanes only
-            out["gat_bwd_src_light<4,16>"] = int(v)
+            coded = k.replace(" ", "").endswith(",true>")
+            out["gat_bwd_src_light" + ("_coded" if coded else "") + "<4,16>"] = int(v)
         if base in BENCH_NAME and "<" in k:
             args = k.split("<", 1)[1].rstrip(">").replace(" ", "").split(",")
             if len(args) == 1:                                  # templated on the head count only
                 args = [args[0], lph_of.get(args[0], "?")]
-            args = args[:2]                                     # (heads, lanes per head); drop further flags
-            out[BENCH_NAME[base] + "<" + ",".join(args) + ">"] = int(v)
+            # (heads, lanes per head); of the further flags only "coded layer input" (the last one of the forward
+            # and source sweeps) is part of the bench name
+            coded = base in ("k_fwd_light", "k_bwd_src_light") and len(args) == 4 and args[3] == "true"
+            out[BENCH_NAME[base] + ("_coded" if coded else "") + "<" + ",".join(args[:2]) + ">"] = int(v)
     if workload == "knn":               # the KNN search: its kernels by their bench names
         out = {}
         for k, v in traffic.items():
