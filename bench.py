@@ -543,6 +543,8 @@ def main():
         if world == 1 and rank == 0:
             torch.cuda.empty_cache()
             knn["embed"] = embed_leg(args, dev)
+            torch.cuda.empty_cache()
+            knn["cadets"] = cadets_leg(args, dev)
 
     # ---- CPU baselines (rank 0, N=1 only)
     cpu_baseline = None
@@ -661,6 +663,27 @@ def embed_leg(args, dev):
         dt = timed(lambda _i: model.embed(g), reps, 1)
     return {"ms_per_graph": round(dt / reps * 1e3, 4), "nodes_per_s": round(n * reps / dt, 1),
             "workload": f"embed() of one E3-Trace-sized graph: N={n} E={g.num_edges()} n_dim={n_dim} hidden={hidden} layers={layers}"}
+
+
+def cadets_leg(args, dev):
+    """The k = 200 search of the cadets evaluation (``model/eval.py:289``) on a bounded sample: lists of that length
+    do not fit the matrix-core filter's lane-per-entry candidate lists, so the whole search runs on the float64
+    matrix-core kernel (buffered candidate sets).  Reported next to the k = 10 leg; not part of its value."""
+    from magic_amd.knn import NearestNeighbors
+    k, d = 200, 64
+    nt, nq = max(4096, int(350_000 * args.scale)), max(512, int(65_536 * args.scale))
+    gen = torch.Generator(device=dev).manual_seed(1006)
+    centers = torch.randn(200, d, device=dev, generator=gen)
+    train = centers[torch.randint(0, 200, (nt,), device=dev, generator=gen)] + 0.05 * torch.randn(nt, d, device=dev, generator=gen)
+    query = centers[torch.randint(0, 200, (nq,), device=dev, generator=gen)] + 0.05 * torch.randn(nq, d, device=dev, generator=gen)
+    nn_ = NearestNeighbors(k, device=dev).fit(train)
+    nn_.mean_distances_device(query[:4096], k)
+    reps = 2
+    dt = timed(lambda _i: nn_.mean_distances_device(query, k), reps, 1)
+    tf = 2.0 * nq * nt * d * reps / dt / 1e12
+    return {"k": k, "ms_per_step": round(dt / reps * 1e3, 3), "queries_per_s": round(nq * reps / dt, 1),
+            "achieved_tflops": round(tf, 2), "frac_of_f64_mfma_peak": round(tf / F64_MFMA_PEAK_TF, 4),
+            "workload": f"k=200 search of {nq} queries against {nt} x {d} train rows, float64 matrix-core kernel"}
 
 
 def knn_leg(args, world, rank, dev, k=10):

@@ -536,7 +536,10 @@ int magic_edge_head_bwd(int64_t n_rows, int32_t width, const float *h_pre, int64
  * short candidate list per query; the float64 keys of the candidates are then recomputed and
  * an error bound proves, per query, that no dropped row can belong to the k nearest.  Queries
  * whose proof fails, searches with lists too long for the filter's LDS and train sets under
- * 4,096 rows take a full sweep on the f64 matrix cores instead.  Either way the reported
+ * 4,096 rows take a full sweep on the f64 matrix cores instead (k = 200 of the cadets
+ * evaluation, model/eval.py:289: every query then owns an unsorted candidate buffer of at
+ * least 2k + 64 entries in the workspace, which its wavefront sorts whenever it fills; the
+ * workspace grows by 12 bytes x buffer size per query and train split).  Either way the reported
  * key of a (query, row) pair comes from one scalar float64 expression, so shard results merge
  * into the single-search result bit for bit.
  * `train_index_offset` is added to every returned index (row offset of this shard of the

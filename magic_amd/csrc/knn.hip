@@ -322,6 +322,264 @@ __global__ __launch_bounds__(256, 2) void k_knn_mfma(KnnArgs a) {
     }
 }
 
+// ---- float64 sweep for long lists (k beyond what LDS holds) -------------------------------------------
+// A sorted list in global memory costs a wave four dependent memory round trips per insertion, and a list of k
+// entries takes k ln(N/k) insertions: 1,500 for k = 200.  Here every query owns an UNSORTED buffer of
+// cap = 64 * NI >= 2k candidates in global memory: a lane whose key is under its query's threshold appends it
+// (the slot comes from a per-query count held in registers and a ballot; the lanes of a tile append side by side,
+// nothing is shifted and nothing is waited for).  When a
+// buffer may overflow in the next train tile (64 rows) its wave sorts it -- entries in registers, NI per lane, a
+// bitonic network over (key, row) with lane shuffles -- keeps the k smallest and tightens the threshold to the
+// k-th key (checked once per 64-row train tile, where few registers are live).  The number of rows between two sorts grows geometrically (the threshold is exact when it is set, so
+// a later row passes with probability k / rows seen): about log(N / cap) / log(cap / k) sorts per query.  What a
+// buffer holds is a set, so the result does not depend on the order of the appends.
+// (bitwise on purpose: the sorting network below is straight-line code of compares and selects)
+__device__ __forceinline__ bool pair_less(double ka, int ia, double kb, int ib) {
+    return (ka < kb) | ((ka == kb) & (ia < ib));
+}
+
+template <int NI>
+__device__ __forceinline__ void wave_sort_pairs(double (&K)[NI], int (&I)[NI], int lane) {
+    constexpr int N = 64 * NI;  // element g = r * 64 + lane
+#pragma unroll
+    for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 64) {  // partner in the same lane, register r ^ (stride / 64)
+                const int rs = stride >> 6;
+#pragma unroll
+                for (int r = 0; r < NI; ++r) {
+                    if ((r & rs) == 0) {
+                        const bool asc = ((r * 64) & size) == 0;
+                        const double k0 = K[r], k1 = K[r | rs];
+                        const int i0 = I[r], i1 = I[r | rs];
+                        const bool sw = pair_less(k1, i1, k0, i0) == asc;
+                        K[r] = sw ? k1 : k0, I[r] = sw ? i1 : i0;
+                        K[r | rs] = sw ? k0 : k1, I[r | rs] = sw ? i0 : i1;
+                    }
+                }
+            } else {  // partner in lane ^ stride, same register
+#pragma unroll
+                for (int r = 0; r < NI; ++r) {
+                    const double ko = __shfl_xor(K[r], stride, 64);
+                    const int io = __shfl_xor(I[r], stride, 64);
+                    const bool keep_min = ((lane & stride) == 0) == ((((r * 64) | lane) & size) == 0);
+                    const bool take = pair_less(ko, io, K[r], I[r]) == keep_min;
+                    K[r] = take ? ko : K[r];
+                    I[r] = take ? io : I[r];
+                }
+            }
+        }
+    }
+}
+
+// Sorts the first n entries of one query's buffer (whole wave, wave-uniform arguments), writes the k smallest
+// back in ascending (key, row) order; returns through `cnt` / `thr` what the query continues with.
+template <int NI>
+__device__ __forceinline__ void buffer_compact(double *bk, int *bi, int n, int k, int lane, int &cnt, double &thr) {
+    double K[NI];
+    int I[NI];
+    __builtin_amdgcn_s_waitcnt(0);  // the appends of this wave have left
+#pragma unroll
+    for (int r = 0; r < NI; ++r) {
+        const int g = r * 64 + lane;
+        K[r] = g < n ? ld_rel<true>(bk + g) : (double)INFINITY;
+        I[r] = g < n ? ld_rel<true>(bi + g) : kIdxNone;
+    }
+    wave_sort_pairs<NI>(K, I, lane);
+    cnt = n < k ? n : k;
+    double t = INFINITY;
+#pragma unroll
+    for (int r = 0; r < NI; ++r) {
+        const int g = r * 64 + lane;
+        if (g < cnt) {
+            st_rel<true>(bk + g, K[r]);
+            st_rel<true>(bi + g, I[r]);
+        }
+        if (r == ((k - 1) >> 6)) t = K[r];
+    }
+    t = __shfl(t, (k - 1) & 63, 64);
+    thr = n >= k ? t : (double)INFINITY;
+    __builtin_amdgcn_s_waitcnt(0);
+}
+
+template <int NI>
+__global__ __launch_bounds__(256, 2) void k_knn_mfma_buf(KnnArgs a, double *buf_key, int *buf_idx) {
+    constexpr int CAP = 64 * NI;
+    extern __shared__ __align__(16) char smem[];
+    float *tile = reinterpret_cast<float *>(smem);                 // TT*LDT floats
+    double *tn = reinterpret_cast<double *>(smem + TT * LDT * 4);  // TT
+    double *thr = tn + TT;                                         // TQ
+    int *cnt = reinterpret_cast<int *>(thr + TQ);                  // TQ
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.y;
+    const int64_t q_base = (int64_t)blockIdx.x * TQ;
+    const int64_t n_active = active_queries(a);
+    if (q_base >= n_active) return;  // uniform: the whole block leaves
+    const int64_t t_lo = (int64_t)split * a.rows_per_split;
+    int64_t t_hi = t_lo + a.rows_per_split;
+    if (t_hi > a.n_train) t_hi = a.n_train;
+    double *B0 = buf_key + ((int64_t)split * a.q_pad + q_base) * CAP;
+    int *J0 = buf_idx + ((int64_t)split * a.q_pad + q_base) * CAP;
+    thr[tid] = INFINITY;
+    cnt[tid] = 0;
+
+    double bq[4][16];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+        int64_t q = q_base + wave * 64 + qb * 16 + (lane & 15);
+        const int d0 = 16 * (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float v = 0.f;
+            if (q < n_active && d0 + j < a.d) v = a.query[query_row(a, q) * a.ld_query + d0 + j];
+            bq[qb][j] = (double)v;
+        }
+    }
+    __syncthreads();
+    const int64_t q_left = n_active - q_base - wave * 64;  // queries of this wave
+    const int nqb = q_left <= 0 ? 0 : (q_left >= 64 ? 4 : (int)((q_left + 15) / 16));
+
+    float4 pre[TT / 16];
+    double pre_tn = (double)INFINITY;
+    auto fetch = [&](int64_t t0) {
+#pragma unroll
+        for (int i = 0; i < TT / 16; ++i) {
+            const int r = (tid >> 4) + 16 * i;
+            const int c4 = (tid & 15) * 4;
+            const int64_t row = t0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < t_hi) {
+                const float *p = a.train + row * a.ld_train + c4;
+                if (c4 + 3 < a.d) {
+                    v = *reinterpret_cast<const float4 *>(p);
+                } else {
+                    if (c4 + 0 < a.d) v.x = p[0];
+                    if (c4 + 1 < a.d) v.y = p[1];
+                    if (c4 + 2 < a.d) v.z = p[2];
+                }
+            }
+            pre[i] = v;
+        }
+        if (tid < TT) pre_tn = (t0 + tid < t_hi) ? a.tnorm[t0 + tid] : (double)INFINITY;
+    };
+    // sort the buffer of the wave's query `ql` (wave-uniform) and publish its new count / threshold
+    auto compact = [&](int ql) {
+        int c;
+        double t;
+        buffer_compact<NI>(B0 + (int64_t)ql * CAP, J0 + (int64_t)ql * CAP, cnt[ql], a.k, lane, c, t);
+        if (lane == 0) {
+            cnt[ql] = c;
+            thr[ql] = t;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // count and threshold of the lane's query in each of the wave's four query tiles, in registers (the same value
+    // in the four lanes of a query); the LDS copies are current at tile boundaries
+    int cnq[4];
+    double thq[4];
+    auto load_state = [&]() {
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            cnq[qb] = cnt[wave * 64 + qb * 16 + (lane & 15)];
+            thq[qb] = thr[wave * 64 + qb * 16 + (lane & 15)];
+        }
+    };
+    load_state();
+    if (t_lo < t_hi) fetch(t_lo);
+    for (int64_t t0 = t_lo; t0 < t_hi; t0 += TT) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TT / 16; ++i)
+            *reinterpret_cast<float4 *>(tile + ((tid >> 4) + 16 * i) * LDT + (tid & 15) * 4) = pre[i];
+        if (tid < TT) tn[tid] = pre_tn;
+        __syncthreads();
+        if (t0 + TT < t_hi) fetch(t0 + TT);
+        // Room for the TT rows of this tile in every buffer.  A wave that sorts keeps its whole block waiting at the
+        // next barrier, so the block sorts together: when any of its 256 buffers is about to overflow, every wave
+        // sorts those of its own buffers that are more than half way there (lane = query).
+        const bool block_full = __any(cnt[lane] > CAP - TT || cnt[64 + lane] > CAP - TT || cnt[128 + lane] > CAP - TT ||
+                                      cnt[192 + lane] > CAP - TT);
+        if (nqb > 0 && block_full) {
+            unsigned long long full = __ballot(cnt[wave * 64 + lane] > a.k + (CAP - TT - a.k) / 2);
+            if (full) {
+                while (full) {
+                    const int l = __ffsll((long long)full) - 1;
+                    full &= full - 1;
+                    compact(wave * 64 + l);
+                }
+                load_state();
+            }
+        }
+
+#pragma unroll 1
+        for (int tb = 0; tb < (nqb > 0 ? TT / 16 : 0); ++tb) {
+            double af[16];
+            {
+                const float *p = tile + (tb * 16 + (lane & 15)) * LDT + 16 * (lane >> 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 v = *reinterpret_cast<const float4 *>(p + 4 * j);
+                    af[4 * j + 0] = (double)v.x;
+                    af[4 * j + 1] = (double)v.y;
+                    af[4 * j + 2] = (double)v.z;
+                    af[4 * j + 3] = (double)v.w;
+                }
+            }
+            double tnr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tnr[r] = tn[tb * 16 + (lane >> 4) + 4 * r];
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) {
+                if (qb >= nqb) continue;  // uniform per wave: no query in this tile
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bq[qb][ks], acc, 0, 0, 0);
+                const int ql = wave * 64 + qb * 16 + (lane & 15);
+                const bool valid = q_base + ql < n_active;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double key = fma(-2.0, acc[r], tnr[r]);
+                    const bool cand = valid && key < thq[qb];
+                    // slots without a round trip: the four lanes of a query count each other's candidates
+                    const unsigned long long m = __ballot(cand);
+                    if (m) {
+                        const unsigned long long col = (m >> (lane & 15)) & 0x0001000100010001ull;
+                        const int below = __popcll(col & ((1ull << (16 * (lane >> 4))) - 1ull));
+                        if (cand) {
+                            const int slot = cnq[qb] + below;
+                            st_rel<true>(B0 + (int64_t)ql * CAP + slot, key);
+                            st_rel<true>(J0 + (int64_t)ql * CAP + slot, (int)(t0 + tb * 16 + (lane >> 4) + 4 * r));
+                        }
+                        cnq[qb] += __popcll(col);
+                    }
+                }
+            }
+        }
+        if (nqb > 0) {  // publish the counts of this tile
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb)
+                if (lane < 16) cnt[wave * 64 + qb * 16 + lane] = cnq[qb];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // the k best of every query, ascending, in the layout the finalize kernels merge
+    double *gk = a.part_key + ((int64_t)split * a.q_pad + q_base) * a.k;
+    int *gi = a.part_idx + ((int64_t)split * a.q_pad + q_base) * a.k;
+    for (int j = 0; j < 64; ++j) {
+        const int ql = wave * 64 + j;
+        if (q_base + ql >= n_active) break;  // uniform
+        compact(ql);
+        const int c = cnt[ql];
+        for (int o = lane; o < a.k; o += 64) {
+            gk[(int64_t)ql * a.k + o] = o < c ? ld_rel<true>(B0 + (int64_t)ql * CAP + o) : (double)INFINITY;
+            gi[(int64_t)ql * a.k + o] = o < c ? ld_rel<true>(J0 + (int64_t)ql * CAP + o) : kIdxNone;
+        }
+    }
+}
+
 // ---- stage 1: approximate keys on the bf16 matrix cores, float32-grade from split operands ---------
 // Every float32 operand is the sum of three bf16 pieces and the six leading cross products are
 // accumulated in float32 (bf16_split.h): 6 x 32 cycles per 32x32x16 step against 4 x 4 x 32 cycles of
@@ -933,6 +1191,14 @@ struct FilterWs {
 size_t lds_bytes(int k, bool lds_lists) {
     return (size_t)TT * LDT * 4 + (size_t)TT * 8 + (size_t)TQ * 8 + (lds_lists ? (size_t)TQ * k * 12 : 0);
 }
+// long lists: registers per lane of the buffered sweep (buffer capacity 64 * NI >= 2k + one train tile), 0 = not
+// served
+int buf_ni(int k) {
+    for (int ni = 2; ni <= 16; ni *= 2)
+        if (64 * ni >= 2 * k + TT) return ni;
+    return 0;
+}
+size_t buf_lds_bytes() { return (size_t)TT * LDT * 4 + (size_t)TT * 8 + (size_t)TQ * 8 + (size_t)TQ * 4; }
 
 void plan_fallback(int64_t n_train, int64_t n_query, int *n_split, int64_t *rows_per_split) {
     // Few queries are expected here, so the train rows are cut finely (up to 16 ways: a block's sweep, the
@@ -999,6 +1265,10 @@ size_t magic_knn_workspace_bytes(int64_t n_train, int64_t n_query, int32_t d, in
         plan_split(n_train, n_query, k, kInsertCostF64, &ns, &rps);
         size_t qpad = (size_t)((n_query + TQ - 1) / TQ) * TQ;
         b += magic::align_up((size_t)ns * qpad * k * 8) + magic::align_up((size_t)ns * qpad * k * 4);
+        if (lds_bytes(k, true) > 64 * 1024 && buf_ni(k) > 0) {
+            const size_t cap = (size_t)64 * buf_ni(k);
+            b += magic::align_up((size_t)ns * qpad * cap * 8) + magic::align_up((size_t)ns * qpad * cap * 4);
+        }
     } else {
         b += magic::align_up((size_t)n_query * (size_t)n_train * 8);  // generic path key matrix
     }
@@ -1099,10 +1369,23 @@ int magic_knn_topk(int64_t n_train, int64_t n_query, int32_t d, int32_t k, const
         a.lds_lists = lds_bytes(k, true) <= 64 * 1024;
         dim3 grid((unsigned)(a.q_pad / TQ), (unsigned)a.n_split);
         size_t sh = lds_bytes(k, a.lds_lists);
-        if (a.lds_lists)
+        const int ni = a.lds_lists ? 0 : buf_ni(k);
+        if (a.lds_lists) {
             MAGIC_LAUNCH("knn_topk_f64_mfma", (k_knn_mfma<false>), grid, 256, sh, stream, a);
-        else
+        } else if (ni > 0) {  // long lists: unsorted candidate buffers, sorted by their wave when they fill
+            const size_t cap = (size_t)64 * ni;
+            double *bkey = ar.take<double>((size_t)a.n_split * a.q_pad * cap);
+            int *bidx = ar.take<int>((size_t)a.n_split * a.q_pad * cap);
+            if (!ar.ok() || !bkey || !bidx) return MAGIC_ERR_WORKSPACE;
+            switch (ni) {
+                case 2: MAGIC_LAUNCH("knn_topk_f64_mfma", (k_knn_mfma_buf<2>), grid, 256, buf_lds_bytes(), stream, a, bkey, bidx); break;
+                case 4: MAGIC_LAUNCH("knn_topk_f64_mfma", (k_knn_mfma_buf<4>), grid, 256, buf_lds_bytes(), stream, a, bkey, bidx); break;
+                case 8: MAGIC_LAUNCH("knn_topk_f64_mfma", (k_knn_mfma_buf<8>), grid, 256, buf_lds_bytes(), stream, a, bkey, bidx); break;
+                default: MAGIC_LAUNCH("knn_topk_f64_mfma", (k_knn_mfma_buf<16>), grid, 256, buf_lds_bytes(), stream, a, bkey, bidx); break;
+            }
+        } else {
             MAGIC_LAUNCH("knn_topk_f64_mfma", (k_knn_mfma<true>), grid, 256, sh, stream, a);
+        }
         MAGIC_LAUNCH("knn_finalize", k_knn_finalize, (unsigned)((n_query + 255) / 256), 256, 0, stream, a, index_offset,
                      dist, idx);
     } else {

@@ -176,6 +176,34 @@ def test_knn_matches_exact_oracle(cuda, nt, nq, d, k):
     assert np.abs(dist.cpu().numpy() - wd).max() < 1e-6     # |q|^2-2qt+|t|^2 vs (q-t)^2 in f64
 
 
+@pytest.mark.parametrize("k", [40, 100, 200, 250, 496, 600])
+@pytest.mark.parametrize("kind", ["random", "duplicates"])
+def test_knn_long_lists(cuda, k, kind):
+    """Lists too long for LDS (the cadets evaluation searches k = 200, model/eval.py:289): candidates are appended to
+    per-query buffers and sorted by their wave when a buffer fills.  Exact float64 answer, ties by row index, for
+    every buffer size the kernel is compiled for (and the sorted global lists beyond them); few queries against
+    many rows, so the train rows are cut into several splits that are merged."""
+    from magic_amd import _lib
+    rng = np.random.default_rng(k)
+    nt, nq, d = 30000, 333, 64
+    if kind == "random":
+        train = rng.standard_normal((nt, d)).astype(np.float32)
+        query = rng.standard_normal((nq, d)).astype(np.float32)
+    else:
+        base = rng.standard_normal((4000, d)).astype(np.float32)
+        train = base[rng.integers(0, 4000, nt)]                     # every row about 7 times: ties by index
+        query = base[rng.integers(0, 4000, nq)] + 0.01
+    dist, idx = _lib.knn_topk(torch.from_numpy(train).to(cuda), torch.from_numpy(query).to(cuda), k)
+    wd, wi = knn_oracle.exact_topk(train, query, k, block=200)
+    assert np.array_equal(idx.cpu().numpy(), wi)
+    assert np.abs(dist.cpu().numpy() - wd).max() < 1e-6
+    # descending train order: every row is a candidate when it arrives (the buffers fill at the highest rate)
+    order = np.argsort(-((train.astype(np.float64) - query[0].astype(np.float64)) ** 2).sum(1), kind="stable")
+    d2, i2 = _lib.knn_topk(torch.from_numpy(train[order]).to(cuda), torch.from_numpy(query[:1]).to(cuda), k)
+    w2d, w2i = knn_oracle.exact_topk(train[order], query[:1], k, block=200)
+    assert np.array_equal(i2.cpu().numpy(), w2i) and np.abs(d2.cpu().numpy() - w2d).max() < 1e-6
+
+
 def test_knn_ties_ordered_by_index_and_merge(cuda):
     from magic_amd import _lib
     rng = np.random.default_rng(1)
