@@ -309,7 +309,8 @@ int magic_coded_weight_grad(int64_t n_nodes, int32_t m, const magic_coded_input 
     // threads, 520 -> three of 192
     const int n_win = (m + 255) / 256;
     const int width = ((m + n_win - 1) / n_win + 63) / 64 * 64;
-    const bool quads = (m & 3) == 0 && (ld_dy & 3) == 0 && ((uintptr_t)dy & 15) == 0 && !getenv("MAGIC_CODED_DW_COLS");
+    static const bool force_cols = getenv("MAGIC_CODED_DW_COLS") != nullptr;  // (comparison runs: tools/ubench/coded_dw.py)
+    const bool quads = (m & 3) == 0 && (ld_dy & 3) == 0 && ((uintptr_t)dy & 15) == 0 && !force_cols;
     if (quads) {
         // column windows of at most 64 quads, equal width: 136 columns -> 34 quads x 7 row slots, 520 -> 3 x (44 x 5)
         const int m4 = m / 4, qwin = (m4 + 63) / 64, wq = (m4 + qwin - 1) / qwin, R = 256 / wq;

@@ -14,11 +14,10 @@ and a uniform non-edge sampler in place of ``dgl.sampling.global_uniform_negativ
 """
 from __future__ import annotations
 
+import os
 import random
 from functools import partial
 from itertools import chain
-
-import os
 
 import torch
 import torch.nn as nn

@@ -415,11 +415,14 @@ def test_custom_ops_are_registered_with_schemas_and_fake_kernels():
     import magic_amd  # noqa: F401
     from torch._subclasses.fake_tensor import FakeTensorMode
     names = ["csr_build", "proj_fwd", "proj_bwd_input", "proj_bwd_input_", "proj_bwd_weight", "gat_fwd_", "gat_bwd_",
-             "sce_fwd_bwd", "sce_loss", "linear_nobias", "knn_topk", "knn_merge", "readout", "negative_filter", "edge_head_fwd", "edge_head_bwd"]
+             "sce_fwd_bwd", "sce_loss", "linear_nobias", "knn_topk", "knn_merge", "readout", "negative_filter", "edge_head_fwd", "edge_head_bwd",
+             "coded_table", "node_code", "gat_fwd_coded_", "gat_bwd_coded_", "coded_weight_grad"]
     for n in names:
         op = getattr(torch.ops.magic, n)
         assert "magic::" + n in str(op.default._schema)
     assert "Tensor(a!) out" in str(torch.ops.magic.gat_fwd_.default._schema)
+    assert "Tensor? dst_active" in str(torch.ops.magic.gat_fwd_.default._schema)
+    assert "Tensor? dst_active" in str(torch.ops.magic.gat_bwd_.default._schema)
     with FakeTensorMode():
         dev = "cuda"
         n, e, h, d = 100, 400, 4, 16

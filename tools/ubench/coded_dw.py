@@ -1,6 +1,7 @@
 """Times the weight gradient of the coded first layer (grouped sum of d_y rows by code word) at the THEIA and
-StreamSpot-batch shapes; MAGIC_CODED_DW_COLS=1 selects the column-per-thread kernel for comparison.
-usage: python tools/ubench/coded_dw.py"""
+StreamSpot-batch shapes and checks it against a float64 sum; MAGIC_CODED_DW_COLS=1 in the environment selects
+the column-per-thread kernel (the fallback for unaligned rows) for comparison.
+usage: python tools/ubench/coded_dw.py ; MAGIC_CODED_DW_COLS=1 python tools/ubench/coded_dw.py"""
 import os
 import sys
 
@@ -23,27 +24,24 @@ def run(n, n_dim, hidden, iters=30):
     tab = _lib.coded_table(w, tok, 1.0 / 0.9)
     ci = _lib.CodedInput(code, tab, tok, n_dim, 1.0 / 0.9)
     dy = torch.randn(n, M, generator=g).to(dev)
-    out = {}
-    for name, env in (("quads", None), ("cols", "1")):
-        if env:
-            os.environ["MAGIC_CODED_DW_COLS"] = env
-        else:
-            os.environ.pop("MAGIC_CODED_DW_COLS", None)
-        for _ in range(3):
-            dw, dt = _lib.coded_weight_grad(ci, dy, w)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            dw, dt = _lib.coded_weight_grad(ci, dy, w)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / iters
-        out[name] = (dw.clone(), dt.clone())
-        print(f"N={n} n_dim={n_dim} M={M} {name}: {us:.1f} us  {(n * M * 4 + n * 4) / us / 1e6:.2f} TB/s", flush=True)
-    a, b = out["quads"], out["cols"]
-    print("  max |dW quads - cols| / max|dW| =", float((a[0] - b[0]).abs().max() / b[0].abs().max()),
-          " d_token:", float((a[1] - b[1]).abs().max() / b[1].abs().max()))
+    name = "cols" if os.environ.get("MAGIC_CODED_DW_COLS") else "quads"
+    for _ in range(3):
+        dw, dt = _lib.coded_weight_grad(ci, dy, w)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        dw, dt = _lib.coded_weight_grad(ci, dy, w)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    print(f"N={n} n_dim={n_dim} M={M} {name}: {us:.1f} us  {(n * M * 4 + n * 4) / us / 1e6:.2f} TB/s", flush=True)
+    # float64 reference: x[u, j] as the first layer sees it, dW = d_y^T x
+    x = torch.nn.functional.one_hot(types, n_dim).double()
+    x[rows] = tok.double()
+    x = x * keep.double() / 0.9
+    ref = dy.double().t() @ x
+    print("  max |dW - float64| / max|dW| =", float((dw.double() - ref).abs().max() / ref.abs().max()))
 
 
 if __name__ == "__main__":
