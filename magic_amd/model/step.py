@@ -50,6 +50,12 @@ def _shared_stream(model):
     return st
 
 
+# Recording must not outlaw what OTHER threads do meanwhile: the process group's watchdog thread polls the events of
+# finished collectives (an event query), which the default ("global") capture mode turns into an error that takes the
+# process down.  Calls of the recording thread itself are still checked.
+_CAPTURE = {"capture_error_mode": "thread_local"}
+
+
 class CapturedTrainStep:
     """``step = CapturedTrainStep(model, optimizer, g); loss = step()`` -- one training step on the
     fixed graph ``g`` per call.
@@ -136,16 +142,16 @@ class CapturedTrainStep:
         torch.cuda.synchronize()
         if self.exchange is None:
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, pool=_shared_pool(self.model), stream=_shared_stream(self.model)):
+            with torch.cuda.graph(gr, pool=_shared_pool(self.model), stream=_shared_stream(self.model), **_CAPTURE):
                 self._forward_backward()
                 if self._capture_opt:
                     self.opt.step()
             graphs = [gr]
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, pool=_shared_pool(self.model), stream=_shared_stream(self.model)):
+            with torch.cuda.graph(ga, pool=_shared_pool(self.model), stream=_shared_stream(self.model), **_CAPTURE):
                 self._forward_backward()
-            with torch.cuda.graph(gb, pool=_shared_pool(self.model), stream=_shared_stream(self.model)):
+            with torch.cuda.graph(gb, pool=_shared_pool(self.model), stream=_shared_stream(self.model), **_CAPTURE):
                 self.opt.step()
             graphs = [ga, gb]
         if {k: v.data_ptr() for k, v in _lib._ws_cache.items()} != ws_before:
