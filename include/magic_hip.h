@@ -146,6 +146,17 @@ typedef struct magic_proj_epilogue {
     float *prelu_grad;                             /* [1] or NULL */
 } magic_proj_epilogue;
 
+/* magic_proj_fwd with the layer's attention vectors given as well (attn_src = attn_h, attn_dst = attn_t of
+ * model/gat.py:291-292, flattened to [out_c], 16-byte aligned): for wide layers with 64-wide heads and no
+ * residual projection the score columns are then formed as the reference forms them, (feat * attn).sum(-1)
+ * over the head's outputs, in the epilogue of the block-tiled kernel -- its 2H extra output columns would cost
+ * a third, nearly idle column block.  w is still the full augmented weight (its folded score rows are used
+ * whenever this shortcut does not apply); same results to fp32 rounding. */
+int magic_proj_fwd_attn(int64_t n_rows, int32_t in_dim, int32_t out_c, int32_t n_score, int32_t res_c,
+                        const float *x, int64_t ld_x, const uint8_t *x_mask, float x_scale, const float *w,
+                        float *hs, int64_t ld_hs, float *score, float *res, int64_t ld_res,
+                        const float *attn_src, const float *attn_dst,
+                        void *workspace, size_t workspace_bytes, void *stream);
 size_t magic_proj_bwd_input_workspace_bytes(int64_t n_rows, int32_t k_dim, int32_t out_dim);
 int magic_proj_bwd_input(int64_t n_rows, int32_t k_dim, int32_t out_dim,
                          const float *dy, int64_t ld_dy, const float *w /* [k_dim,out_dim] */,

@@ -56,6 +56,8 @@ SYMBOLS = {
     "magic_adam_step": (c_i32, [c_i32, c_vp, c_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_vp]),
     "magic_proj_fwd": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_i64,
                                c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "magic_proj_fwd_attn": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_i64,
+                                    c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "magic_proj_fwd_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "magic_proj_bwd_input_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
     "magic_proj_bwd_input": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
@@ -388,8 +390,11 @@ def _rows(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 def proj_fwd(x: torch.Tensor, w: torch.Tensor, out_c: int, n_score: int, res_c: int,
-             x_mask: Optional[torch.Tensor] = None, x_scale: float = 1.0):
-    """hs [N,out_c], score [N,n_score] | None, res [N,res_c] | None  =  split((x * mask * scale) @ w.T)."""
+             x_mask: Optional[torch.Tensor] = None, x_scale: float = 1.0,
+             attn_src: Optional[torch.Tensor] = None, attn_dst: Optional[torch.Tensor] = None):
+    """hs [N,out_c], score [N,n_score] | None, res [N,res_c] | None  =  split((x * mask * scale) @ w.T).
+    ``attn_src`` / ``attn_dst`` ([out_c] each, the layer's ``attn_h`` / ``attn_t``): lets wide layers form the score
+    columns from the output rows (``magic_proj_fwd_attn``); ``w`` stays the full augmented weight."""
     lib = load()
     assert x.dim() == 2 and w.dim() == 2 and w.shape[1] == x.shape[1] and w.shape[0] == out_c + n_score + res_c
     x = _rows(x)
@@ -402,9 +407,17 @@ def proj_fwd(x: torch.Tensor, w: torch.Tensor, out_c: int, n_score: int, res_c: 
     score = torch.empty(N, n_score, dtype=torch.float32, device=dev) if n_score else None
     res = torch.empty(N, res_c, dtype=torch.float32, device=dev) if res_c else None
     ws = workspace(lib.magic_proj_fwd_workspace_bytes(F, out_c + n_score + res_c), dev)
-    _check(lib.magic_proj_fwd(N, F, out_c, n_score, res_c, _dev(x, torch.float32, "x"), x.stride(0),
-                              _dev(x_mask), float(x_scale), _dev(w, torch.float32, "w"), _dev(hs), out_c,
-                              _dev(score), _dev(res), res_c, ws.data_ptr(), ws.numel(), _stream()), "magic_proj_fwd")
+    head = (N, F, out_c, n_score, res_c, _dev(x, torch.float32, "x"), x.stride(0), _dev(x_mask), float(x_scale),
+            _dev(w, torch.float32, "w"), _dev(hs), out_c, _dev(score), _dev(res), res_c)
+    if attn_src is not None and attn_dst is not None:
+        attn_src, attn_dst = attn_src.detach().reshape(-1).contiguous(), attn_dst.detach().reshape(-1).contiguous()
+        if attn_src.numel() != out_c or attn_dst.numel() != out_c:
+            raise MagicHipError("attn_src / attn_dst must hold one entry per output column")
+        _check(lib.magic_proj_fwd_attn(*head, _dev(attn_src, torch.float32, "attn_src"),
+                                       _dev(attn_dst, torch.float32, "attn_dst"), ws.data_ptr(), ws.numel(), _stream()),
+               "magic_proj_fwd_attn")
+    else:
+        _check(lib.magic_proj_fwd(*head, ws.data_ptr(), ws.numel(), _stream()), "magic_proj_fwd")
     return hs, score, res
 
 

@@ -33,6 +33,10 @@ struct ProjArgs {
     const float *prelu_w;  // device scalar
     float *part_col;       // [n_part, C] per-wave column sums (or null)
     float *part_prelu;     // [n_part]
+    // Head scores from the output row (model/gat.py:291-292: (feat * attn).sum(-1)) instead of from folded weight
+    // rows: per output column the attention vector entries of the node as a source / as a destination, [C] each.
+    // Set by the dispatcher only for the block-tiled kernel with 64-wide heads; M then excludes the score columns.
+    const float *sc_src, *sc_dst;
 };
 
 }  // namespace magic

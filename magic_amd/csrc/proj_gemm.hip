@@ -218,6 +218,14 @@ __global__ __launch_bounds__(256, 2) void k_proj_gemm(ProjArgs a, GemmPlan p) {
     Dst d;
     d.p = nullptr, d.ld = 0, d.mode = 0;
     if (!EP) d = route(a, gc);
+    // head scores from the output rows: this wave's 64 columns are one head (64-wide heads only)
+    const bool scores = !EP && a.sc_src != nullptr;
+    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f), dv = sv;
+    if (scores && gc + 4 <= a.C) {
+        sv = *reinterpret_cast<const float4 *>(a.sc_src + gc);
+        dv = *reinterpret_cast<const float4 *>(a.sc_dst + gc);
+    }
+    const int head = (colb + wc * 64) >> 6, n_heads = a.NS >> 1;
     if (tile_ok[0]) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {  // 16 rows x 64 columns through the strip
@@ -234,9 +242,24 @@ __global__ __launch_bounds__(256, 2) void k_proj_gemm(ProjArgs a, GemmPlan p) {
                 const int64_t orow = row0 + wr * 64 + rt * SR + r;
                 if (EP) {
                     if (gc < a.C) epi_store4<true>(a, q, orow, gc, w, inv_w, cs4, dprelu);
-                } else if (orow < a.n) {
-                    if (d.mode == 1) *reinterpret_cast<float4 *>(d.p + orow * d.ld) = q;
-                    if (d.mode == 2) route_store_elems(a, q, orow, gc);
+                } else {
+                    if (orow < a.n) {
+                        if (d.mode == 1) *reinterpret_cast<float4 *>(d.p + orow * d.ld) = q;
+                        if (d.mode == 2) route_store_elems(a, q, orow, gc);
+                    }
+                    if (scores) {  // (all lanes take part in the shuffles; 16 lanes hold one row)
+                        float ps = fmaf(q.w, sv.w, fmaf(q.z, sv.z, fmaf(q.y, sv.y, q.x * sv.x)));
+                        float pd = fmaf(q.w, dv.w, fmaf(q.z, dv.z, fmaf(q.y, dv.y, q.x * dv.x)));
+#pragma unroll
+                        for (int off = 1; off < 16; off <<= 1) {
+                            ps += __shfl_xor(ps, off, 64);
+                            pd += __shfl_xor(pd, off, 64);
+                        }
+                        if ((lane & 15) == 0 && orow < a.n && head < n_heads) {
+                            a.score[orow * a.NS + head] = ps;
+                            a.score[orow * a.NS + n_heads + head] = pd;
+                        }
+                    }
                 }
             }
         }

@@ -256,8 +256,12 @@ class GMAEModel(nn.Module):
         n = g.num_nodes()
         widths = [enc[0].src_feat] + [H * D] * (len(enc) - 1) + [d.src_feat]
         masks, scale = self._dropout_masks(widths, n, g.device, drop_masks, drop_seeds)
-        return FusedCfg(g.structure.ensure_csr(), etype, g.edge_types_csr(), enc[0].edge_feat, len(enc), H, D, d.out_feat,
-                        _pad_head_dim(d.out_feat), enc[0].leaky_relu.negative_slope, res_kinds, masks, scale)
+        cfg = FusedCfg(g.structure.ensure_csr(), etype, g.edge_types_csr(), enc[0].edge_feat, len(enc), H, D, d.out_feat,
+                       _pad_head_dim(d.out_feat), enc[0].leaky_relu.negative_slope, res_kinds, masks, scale)
+        if D == 64 and os.environ.get("MAGIC_PROJ_ATTN", "1") != "0":   # (head width the scores-from-the-output-row
+            # shortcut of the projection serves)
+            cfg.attn = [(layer.attn_h, layer.attn_t) for layer in enc]
+        return cfg
 
     def _edge_recon_loss(self, pairs, n_pos, n_neg, neg_valid):
         """The BCE of ``model/autoencoder.py:257-266`` on the library: the head's first layer as one projection of

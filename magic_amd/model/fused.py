@@ -53,6 +53,9 @@ class FusedCfg:
         # uint8 [N]: the rows of the reconstruction the caller reads (the masked nodes of the loss); the decoder's
         # sweeps then visit the edges into those rows only.  None: every row is produced.
         self.recon_rows = None
+        # per encoder layer (attn_h, attn_t) or None: lets the projection of a wide layer form the head scores from
+        # its output rows (values only; their gradients come out of the augmented weight's folded rows)
+        self.attn = None
 
     def coded(self, token) -> bool:
         return (self.node_types is not None and token is not None and self.res_kinds[0] == "linear" and self.H == 4
@@ -100,7 +103,7 @@ class FusedGMAEFn(torch.autograd.Function):
                 inp = out_l
                 continue
             hs, score, res = ops.proj_fwd(inp, w_aug, C, 2 * H, C if kind == "linear" else 0,
-                                           x_mask=mask, x_scale=cfg.scale)
+                                           x_mask=mask, x_scale=cfg.scale, attn=cfg.attn[l] if cfg.attn else None)
             res_mask = None
             if kind == "identity":
                 res, res_mask = inp, mask

@@ -120,7 +120,7 @@ class _GATLayerFn(torch.autograd.Function):
         H, Dp, C = cfg["H"], cfg["Dp"], cfg["C"]
         res_c = cfg["res_c"]
         h = h.contiguous() if h.stride(-1) != 1 else h
-        hs, score, res = ops.proj_fwd(h, w_aug, C, 2 * H, res_c)
+        hs, score, res = ops.proj_fwd(h, w_aug, C, 2 * H, res_c, attn=cfg.get("attn"))
         if cfg["res_identity"]:
             res = h
         etype = cfg["etype_csc"]
@@ -346,7 +346,8 @@ class GATConv(nn.Module):
                    res_identity=res_identity, etype_csc=etype_csc,
                    etype_csr=graph.edge_types_csr() if need_grad else None, e_dim=self.edge_feat,
                    slope=self.leaky_relu.negative_slope, has_bias=bias is not None, need_grad=need_grad,
-                   want_attn=bool(get_attention))
+                   want_attn=bool(get_attention),
+                   attn=(self.attn_h, self.attn_t) if D == 64 and Dp == D else None)
         out, attn = _GATLayerFn.apply(h, w_aug, edge_term, bias, prelu_w, struct, cfg)
         rst = out
         if Dp != D:

@@ -83,19 +83,20 @@ _register("negative_filter", "(Tensor out_ptr, Tensor out_dst, Tensor in_ptr, Te
 
 
 # ------------------------------------------------------------------------------------- projections
-def _proj_fwd(x, w, out_c: int, n_score: int, res_c: int, x_mask, x_scale: float):
-    hs, score, res = _lib.proj_fwd(x, w, out_c, n_score, res_c, x_mask=x_mask, x_scale=x_scale)
+def _proj_fwd(x, w, out_c: int, n_score: int, res_c: int, x_mask, x_scale: float, attn_src, attn_dst):
+    hs, score, res = _lib.proj_fwd(x, w, out_c, n_score, res_c, x_mask=x_mask, x_scale=x_scale, attn_src=attn_src,
+                                   attn_dst=attn_dst)
     return hs, score if score is not None else _empty(x), res if res is not None else _empty(x)
 
 
-def _proj_fwd_fake(x, w, out_c, n_score, res_c, x_mask, x_scale):
+def _proj_fwd_fake(x, w, out_c, n_score, res_c, x_mask, x_scale, attn_src, attn_dst):
     n = x.shape[0]
     return (x.new_empty(n, out_c), x.new_empty((n, n_score) if n_score else (0,)),
             x.new_empty((n, res_c) if res_c else (0,)))
 
 
-_register("proj_fwd", "(Tensor x, Tensor w, int out_c, int n_score, int res_c, Tensor? x_mask, float x_scale) "
-          "-> (Tensor, Tensor, Tensor)", _proj_fwd, _proj_fwd_fake)
+_register("proj_fwd", "(Tensor x, Tensor w, int out_c, int n_score, int res_c, Tensor? x_mask, float x_scale, "
+          "Tensor? attn_src, Tensor? attn_dst) -> (Tensor, Tensor, Tensor)", _proj_fwd, _proj_fwd_fake)
 
 
 def _proj_bwd_input(dy, w, add, out_mask, out_scale: float, add2, act_out, act_pre, prelu_w, want_col_sum: bool):
@@ -340,8 +341,10 @@ def coded_weight_grad(cd: Coded, d_y, w_aug):
     return torch.ops.magic.coded_weight_grad(cd.code, cd.table, cd.token, cd.scale, d_y, w_aug)
 
 
-def proj_fwd(x, w, out_c, n_score, res_c, x_mask=None, x_scale=1.0):
-    hs, score, res = torch.ops.magic.proj_fwd(x, w, out_c, n_score, res_c, x_mask, float(x_scale))
+def proj_fwd(x, w, out_c, n_score, res_c, x_mask=None, x_scale=1.0, attn=None):
+    """``attn``: (attn_h, attn_t) of the layer, any shape with out_c elements (see ``_lib.proj_fwd``)."""
+    a_s, a_d = (None, None) if attn is None else (attn[0].detach().reshape(-1), attn[1].detach().reshape(-1))
+    hs, score, res = torch.ops.magic.proj_fwd(x, w, out_c, n_score, res_c, x_mask, float(x_scale), a_s, a_d)
     return hs, _none(score), _none(res)
 
 

@@ -446,7 +446,7 @@ def test_custom_ops_are_registered_with_schemas_and_fake_kernels():
         dist, idx = torch.ops.magic.knn_topk(f(1000, 64), f(37, 64), 10, 0)
         assert dist.shape == (37, 10) and dist.dtype == torch.float64 and idx.dtype == torch.int64
         assert torch.ops.magic.readout(f(n, 256), torch.empty(n, dtype=torch.int64, device=dev), 8, True).shape == (1, 2048)
-        hs, score, res = torch.ops.magic.proj_fwd(f(n, 8), f(64 + 8 + 64, 8), 64, 8, 64, None, 1.0)
+        hs, score, res = torch.ops.magic.proj_fwd(f(n, 8), f(64 + 8 + 64, 8), 64, 8, 64, None, 1.0, None, None)
         assert hs.shape == (n, 64) and score.shape == (n, 8) and res.shape == (n, 64)
         loss, d_x, d_t = torch.ops.magic.sce_fwd_bwd(f(n, 8), 5, f(1, 5), True, torch.empty(50, dtype=torch.int64, device=dev), 3.0)
         assert loss.shape == (1,) and d_x.shape == (n, 8) and d_t.shape == (5,)

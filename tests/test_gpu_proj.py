@@ -128,3 +128,36 @@ def test_proj_bwd_weight_against_float64(cuda, n, m_, f, mask):
     err = (dw.double() - ref).abs()
     assert bool((err <= bound).all()), float((err / bound).max())
     assert torch.equal(dw, _lib.proj_bwd_weight(dy, x, x_mask=m, x_scale=scale))
+
+
+@pytest.mark.parametrize("n,F,H", [(5000, 256, 4), (777, 1024, 4), (3000, 128, 2)])
+def test_head_scores_from_the_output_rows(cuda, n, F, H):
+    """magic_proj_fwd_attn: wide layers with 64-wide heads form eh / et as (feat * attn).sum(-1) over the head's outputs
+    (model/gat.py:291-292) in the projection's epilogue instead of through folded weight rows: same hs bit for bit,
+    scores equal to float64 to the bound of the other projection kernels; shapes the shortcut does not serve fall back
+    to the folded rows."""
+    from magic_amd import _lib
+    D = 64
+    C = H * D
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, F, generator=g).to(cuda)
+    w_fc = torch.randn(C, F, generator=g).to(cuda) / F ** 0.5
+    a_h, a_t = torch.randn(1, H, D, generator=g).to(cuda), torch.randn(1, H, D, generator=g).to(cuda)
+    fold = lambda a: (w_fc.view(H, D, F) * a.view(H, D, 1)).sum(1)   # noqa: E731
+    w_aug = torch.cat([w_fc, fold(a_h), fold(a_t)], 0).contiguous()
+    mask = (torch.rand(n, F, generator=g) < 0.9).to(torch.uint8).to(cuda)
+    hs0, sc0, _ = _lib.proj_fwd(x, w_aug, C, 2 * H, 0, x_mask=mask, x_scale=1 / 0.9)
+    hs1, sc1, _ = _lib.proj_fwd(x, w_aug, C, 2 * H, 0, x_mask=mask, x_scale=1 / 0.9, attn_src=a_h, attn_dst=a_t)
+    assert torch.equal(hs0, hs1)
+    xd = (x.double() * mask.double() / 0.9)
+    hsd = xd @ w_fc.double().t()
+    want = torch.cat([(hsd.view(n, H, D) * a_h.double()).sum(-1), (hsd.view(n, H, D) * a_t.double()).sum(-1)], 1)
+    mag = torch.cat([(xd.abs() @ w_fc.double().abs().t()).view(n, H, D).mul(a.double().abs()).sum(-1) for a in (a_h, a_t)], 1)
+    for sc in (sc0, sc1):
+        assert float(((sc.double() - want).abs() / mag).max()) < 4e-6
+    # a linear residual (extra output columns) is not served by the shortcut: the folded rows are used
+    w_res = torch.randn(C, F, generator=g).to(cuda)
+    w2 = torch.cat([w_aug, w_res], 0).contiguous()
+    h2, s2, r2 = _lib.proj_fwd(x, w2, C, 2 * H, C, attn_src=a_h, attn_dst=a_t)
+    h3, s3, r3 = _lib.proj_fwd(x, w2, C, 2 * H, C)
+    assert torch.equal(h2, h3) and torch.equal(s2, s3) and torch.equal(r2, r3)

@@ -27,7 +27,7 @@ def timeit(fn, reps=20):
     return s.elapsed_time(e) / reps * 1e3
 
 
-for (k, m) in [(8, 520), (256, 264), (264, 256), (1024, 256), (256, 1024), (256, 10), (64, 72), (72, 64)]:
+for (k, m) in [(8, 520), (256, 264), (256, 256), (264, 256), (1024, 256), (256, 1024), (256, 10), (64, 72), (72, 64)]:
     x = torch.randn(N, k, device=dev)
     w = torch.randn(m, k, device=dev)
     fl = 2.0 * N * k * m
