@@ -46,6 +46,12 @@ int main() {
            MAGIC_OK);
     EXPECT(magic_proj_fwd(4, 8, 8, 2, 0, dummy, 4, nullptr, 1.f, dummy, dummy, 8, nullptr, nullptr, 0, nullptr, 0, nullptr),
            MAGIC_ERR_INVALID_ARG);  // ld_x < in_dim
+    EXPECT(magic_proj_fwd_attn(-1, 8, 8, 0, 0, dummy, 8, nullptr, 1.f, dummy, dummy, 8, nullptr, nullptr, 0, dummy, dummy,
+                               nullptr, 0, nullptr),
+           MAGIC_ERR_INVALID_ARG);
+    EXPECT(magic_proj_fwd_attn(4, 8, 8, 2, 0, dummy, 8, nullptr, 1.f, dummy, dummy, 8, nullptr, nullptr, 0, dummy, dummy,
+                               nullptr, 0, nullptr),
+           MAGIC_ERR_INVALID_ARG);  // score columns asked for, no score output
     (void)magic_proj_fwd_workspace_bytes(256, 264);
     (void)magic_proj_bwd_input_workspace_bytes(1000, 264, 256);
     (void)magic_proj_bwd_weight_workspace_bytes(1000, 264, 256);
