@@ -140,6 +140,37 @@ def test_knn_properties_full_size(cuda):
     assert torch.equal(mi, idx) and torch.equal(md, dist)
 
 
+def test_knn_long_lists_properties_at_cadets_size(cuda):
+    """k = 200 (model/eval.py:289) at the size of a cadets evaluation: 350,000 train rows, 32,768 queries.  Ascending
+    lists, a train row finds itself, the distances are what the indices say, a float64 brute force of a query sample
+    gives the same lists, and two half shards merge into the single-search answer bit for bit."""
+    from magic_amd.knn import NearestNeighbors, merge_topk
+    nt, nq, d, k = 350_000, 32_768, 64, 200
+    gen = torch.Generator(device=cuda).manual_seed(6)
+    centers = torch.randn(200, d, device=cuda, generator=gen)
+    train = centers[torch.randint(0, 200, (nt,), device=cuda, generator=gen)] + \
+        0.05 * torch.randn(nt, d, device=cuda, generator=gen)
+    rows = torch.randint(0, nt, (nq,), device=cuda, generator=gen)
+    query = train[rows].clone()
+    dist, idx = NearestNeighbors(k, device=cuda).fit(train).kneighbors_device(query, k)
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())
+    assert torch.equal(idx[:, 0], rows) and float(dist[:, 0].max()) < 1e-3
+    assert bool((idx.sort(1).values[:, 1:] != idx.sort(1).values[:, :-1]).all())      # no row twice
+    sel = torch.arange(0, nq, 257, device=cuda)
+    chk = (query[sel].double().unsqueeze(1) - train[idx[sel]].double()).pow(2).sum(-1).sqrt()
+    assert float((chk - dist[sel]).abs().max()) < 1e-5
+    full = torch.cdist(query[sel].double(), train.double())                          # [128, 350000] float64
+    want_d, want_i = full.topk(k, dim=1, largest=False)
+    assert float((want_d - dist[sel]).abs().max()) < 1e-6
+    assert float((want_i == idx[sel]).double().mean()) > 0.999      # (float64 near-ties of the two formulas may swap)
+    half = nt // 2
+    parts = []
+    for lo, hi in ((0, half), (half, nt)):
+        parts.append(NearestNeighbors(k, device=cuda).fit(train[lo:hi]).kneighbors_device(query, k, index_offset=lo))
+    md, mi = merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(mi, idx) and torch.equal(md, dist)
+
+
 def test_streamspot_batch_step_reproducible_and_directional_derivative(cuda):
     """The benchmark's default workload (a batch of 12 StreamSpot-sized graphs, hidden 256, 4 layers:
     the wide-layer kernels): union CSR equal to a direct sort, bitwise reproducible step, and the
