@@ -331,15 +331,16 @@ class Graph:
         self._onehot_edge = (weakref.ref(attr), attr._version)
 
     def _node_attr_marked(self) -> bool:
-        m, attr = self._onehot_node, self.ndata.get("attr")
-        return m is not None and attr is not None and m[0]() is attr and m[1] == attr._version
+        m, attr, typ = self._onehot_node, self.ndata.get("attr"), self.ndata.get("type")
+        return (m is not None and attr is not None and typ is not None and m[0]() is attr and m[1] == attr._version
+                and m[2]() is typ and m[3] == typ._version)
 
     def mark_node_attr_onehot(self):
         """Declare that ``ndata['attr']`` was just built as ``one_hot(ndata['type'])``
-        (``utils/loaddata.py:258``).  The mark dies with any later write to, or rebinding of, the tensor
+        (``utils/loaddata.py:258``).  The mark dies with any later write to, or rebinding of, either tensor
         (the masking step's token write included: it is read before that write)."""
-        attr = self.ndata["attr"]
-        self._onehot_node = (weakref.ref(attr), attr._version)
+        attr, typ = self.ndata["attr"], self.ndata["type"]
+        self._onehot_node = (weakref.ref(attr), attr._version, weakref.ref(typ), typ._version)
 
     def node_types_if_onehot(self) -> Optional[torch.Tensor]:
         """``ndata['type']`` (int64 [N]) while ``ndata['attr']`` is known to be its one-hot, else None."""
