@@ -726,3 +726,22 @@ def test_decoder_restricted_to_the_masked_rows_changes_nothing(cuda, shape):
     assert set(outs[0][1]) == set(outs[1][1])
     for k in outs[0][1]:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_onehot_node_mark_dies_with_writes(cuda):
+    """The coded first layer trusts ``ndata['attr'] == one_hot(ndata['type'])`` only while both tensors are the very
+    objects that were marked, unwritten; clones and device copies keep the mark."""
+    n, e, n_dim, e_dim = 200, 600, 5, 7
+    src, dst, ntype, etype = small_graph(n, e, n_dim, e_dim, seed=2)
+    g = to_graph(src, dst, n, ntype, etype, n_dim, e_dim, cuda)
+    assert torch.equal(g.node_types_if_onehot().cpu(), torch.from_numpy(ntype))
+    assert g.clone().node_types_if_onehot() is not None
+    g1 = to_graph(src, dst, n, ntype, etype, n_dim, e_dim, cuda)
+    g1.ndata["attr"][0, 0] += 0.0
+    assert g1.node_types_if_onehot() is None
+    g2 = to_graph(src, dst, n, ntype, etype, n_dim, e_dim, cuda)
+    g2.ndata["type"][0] = (g2.ndata["type"][0] + 1) % n_dim
+    assert g2.node_types_if_onehot() is None
+    g3 = to_graph(src, dst, n, ntype, etype, n_dim, e_dim, cuda)
+    g3.ndata["type"] = g3.ndata["type"].clone()
+    assert g3.node_types_if_onehot() is None
