@@ -581,3 +581,42 @@ def test_oracle_sparse_ops_match_scipy_sparse_products():
         seg = np.stack([inc @ ag[:, h] for h in range(heads)], 1)
         want_grad = ag - at.detach().numpy()[:, :, 0] * seg[dst]
         assert np.abs(lt.grad.numpy()[:, :, 0] - want_grad).max() < 1e-12
+
+
+def test_oracle_gat_layer_matches_a_dense_adjacency_restatement():
+    """Second, independently shaped statement of the layer ``oracle.GATConv`` restates (``model/gat.py:284-335``): a
+    dense [N, N, H] logit array with -inf where there is no edge, a row softmax over sources, and an einsum for the
+    aggregation -- no edge lists, no segment operators.  Duplicate-free graphs only (a dense array holds one edge per
+    pair); nodes without in-edges, self-loops, a hub, both residual kinds and the activation are covered."""
+    torch.manual_seed(3)
+    rng = np.random.default_rng(9)
+    n, n_dim, e_dim, H, D = 37, 6, 5, 4, 8
+    pairs = {(int(a), int(b)) for a, b in zip(rng.integers(0, n, 260), rng.integers(0, n, 260))}
+    pairs |= {(u, 3) for u in range(0, n, 2)} | {(5, 5), (9, 9)}           # a hub and two self-loops
+    pairs = sorted(p for p in pairs if p[1] not in (0, 1, 2))               # nodes 0..2 keep no in-edge
+    src = torch.tensor([p[0] for p in pairs])
+    dst = torch.tensor([p[1] for p in pairs])
+    for in_dim in (n_dim, H * D):                                           # linear / identity residual
+        g = O.OGraph(src, dst, n)
+        etype = torch.from_numpy(rng.integers(0, e_dim, len(pairs)))
+        g.edata["attr"] = torch.nn.functional.one_hot(etype, e_dim).double()
+        layer = O.GATConv(in_dim, e_dim, D, H, residual=True, activation=torch.nn.PReLU(), negative_slope=0.2).double()
+        with torch.no_grad():
+            layer.bias.normal_()
+        x = torch.randn(n, in_dim, dtype=torch.float64)
+        got, attn = layer(g, x, get_attention=True)
+        # dense restatement
+        feat = (x @ layer.fc.weight.t()).view(n, H, D)
+        eh = (feat * layer.attn_h[0]).sum(-1)                               # [N, H] score as a source
+        et = (feat * layer.attn_t[0]).sum(-1)                               # [N, H] score as a destination
+        ee_type = ((layer.edge_fc.weight.t().view(e_dim, H, D)) * layer.attn_e[0]).sum(-1)   # [e_dim, H]
+        logit = torch.full((n, n, H), -float("inf"), dtype=torch.float64)   # [dst, src, head]
+        logit[dst, src] = torch.nn.functional.leaky_relu(eh[src] + ee_type[etype] + et[dst], 0.2)
+        w = torch.softmax(logit, dim=1)
+        w = torch.where(torch.isnan(w), torch.zeros_like(w), w)            # rows without any edge
+        out = torch.einsum("vuh,uhd->vhd", w, feat) + layer.bias.view(1, H, D)
+        res = x.view(n, H, D) if in_dim == H * D else (x @ layer.res_fc.weight.t()).view(n, H, D)
+        want = layer.activation((out + res).flatten(1))
+        assert float((got - want).abs().max()) < 1e-12
+        assert float((attn.squeeze(-1) - w[dst, src]).abs().max()) < 1e-14
+        assert float(out[:3].sub(layer.bias.view(1, H, D)).abs().max()) == 0.0      # no in-edges: bias + residual only
